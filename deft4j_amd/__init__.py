@@ -1,0 +1,277 @@
+"""deft4j_amd — host-side mirror of deft4j's optimiser API over libdeft4g.so (HIP, gfx950).
+
+The Java reference (NeRdTheNed/deft4j) exposes
+    Deft.optimiseDeflateStream(byte[], boolean)            B/Deft.java:21-34
+    Deft.getSizeBitsFallback(byte[])                       B/Deft.java:48-54
+    DeflateStream.parse / optimise / getSizeBits / getUncompressedData / asBytes
+                                                           B/deflate/DeflateStream.java:68-182,496,652
+    DeflateFilesContainer.optimise(List<DeflateStream>, boolean)   K/DeflateFilesContainer.java:18-43
+(B/ = deft4j-base/src/main/java/com/github/NeRdTheNed/deft4j/, K/ = deft4j-container/...).
+This module keeps those names, argument meanings and the "fall back to the original bytes"
+error behaviour, and forwards every call to the C ABI declared in include/deft4g.h.  There
+is no CPU path here: importing works anywhere, but any call raises RuntimeError unless the
+HIP library is built and a GPU is present.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeft4g.so")
+
+_lib = None
+_ready = False
+
+
+class d4g_stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("ms_upload", "ms_parse", "ms_optimise", "ms_merge", "ms_write", "ms_total")] + \
+               [(n, ctypes.c_int64) for n in ("n_streams", "n_blocks", "n_tokens", "bytes_in", "bytes_decoded", "bytes_out",
+                                              "rounds", "kernel_launches", "search_bytes_algorithmic")] + \
+               [("ms_search_kernels", ctypes.c_double)]
+
+
+EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",
+           "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
+           "d4g_size_bits_fallback", "d4g_inflate", "d4g_free"]
+
+
+def load_library(path=None):
+    """Load libdeft4g.so and declare the prototypes of include/deft4g.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("libdeft4g.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback" % p)
+    L = ctypes.CDLL(p)
+    L.d4g_init.restype = ctypes.c_int
+    L.d4g_init.argtypes = [ctypes.c_int]
+    L.d4g_shutdown.restype = None
+    L.d4g_last_error.restype = ctypes.c_char_p
+    L.d4g_batch_create.restype = ctypes.c_void_p
+    L.d4g_batch_create.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_batch_run.restype = ctypes.c_int
+    L.d4g_batch_run.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.d4g_batch_stream_result.restype = ctypes.c_int
+    L.d4g_batch_stream_result.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_size_t),
+                                          ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int64)]
+    L.d4g_batch_copy_output.restype = ctypes.c_int
+    L.d4g_batch_copy_output.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.d4g_batch_copy_decoded.restype = ctypes.c_int
+    L.d4g_batch_copy_decoded.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_batch_stats.restype = ctypes.c_int
+    L.d4g_batch_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(d4g_stats)]
+    L.d4g_batch_destroy.restype = None
+    L.d4g_batch_destroy.argtypes = [ctypes.c_void_p]
+    L.d4g_free.restype = None
+    L.d4g_free.argtypes = [ctypes.c_void_p]
+    if path is None:
+        _lib = L
+    return L
+
+
+def init(device_index=None, lib=None):
+    """d4g_init: one process per GPU.  Defaults to LOCAL_RANK (torch.distributed launch) or 0."""
+    global _ready
+    L = lib or load_library()
+    if device_index is None:
+        device_index = int(os.environ.get("LOCAL_RANK", "0"))
+    rc = L.d4g_init(device_index)
+    if rc != 0:
+        raise RuntimeError("d4g_init(%d) failed: %s" % (device_index, L.d4g_last_error().decode()))
+    if lib is None:
+        _ready = True
+    return L
+
+
+def _need():
+    if not _ready:
+        init()
+    return _lib
+
+
+class Batch:
+    """A list of independent raw DEFLATE streams resident in HBM (d4g_batch_*)."""
+
+    def __init__(self, streams, lib=None):
+        self.L = lib or _need()
+        self.n = len(streams)
+        self._keep = [bytes(s) for s in streams]
+        arr = (ctypes.c_char_p * self.n)(*self._keep)
+        lens = (ctypes.c_size_t * self.n)(*[len(s) for s in self._keep])
+        self.h = self.L.d4g_batch_create(self.n, arr, lens)
+        if not self.h:
+            raise RuntimeError("d4g_batch_create: " + self.L.d4g_last_error().decode())
+
+    def run(self, merge_blocks=True):
+        rc = self.L.d4g_batch_run(self.h, 1 if merge_blocks else 0)
+        if rc != 0:
+            raise RuntimeError("d4g_batch_run: " + self.L.d4g_last_error().decode())
+        return self
+
+    def result(self, i):
+        """-> dict(status, saved_bits, out_len, consumed, size_bits_in)"""
+        st = ctypes.c_int32()
+        sv = ctypes.c_int64()
+        ol = ctypes.c_size_t()
+        co = ctypes.c_size_t()
+        sb = ctypes.c_int64()
+        rc = self.L.d4g_batch_stream_result(self.h, i, ctypes.byref(st), ctypes.byref(sv), ctypes.byref(ol),
+                                            ctypes.byref(co), ctypes.byref(sb))
+        if rc != 0:
+            raise RuntimeError(self.L.d4g_last_error().decode())
+        return dict(status=st.value, saved_bits=sv.value, out_len=ol.value, consumed=co.value, size_bits_in=sb.value)
+
+    def output(self, i):
+        """DeflateStream.asBytes() of stream i (the re-serialised stream, whether or not bits were saved)."""
+        r = self.result(i)
+        buf = ctypes.create_string_buffer(max(1, r["out_len"]))
+        rc = self.L.d4g_batch_copy_output(self.h, i, buf, r["out_len"])
+        if rc != 0:
+            raise RuntimeError(self.L.d4g_last_error().decode())
+        return buf.raw[:r["out_len"]]
+
+    def decoded(self, i):
+        n = ctypes.c_size_t()
+        rc = self.L.d4g_batch_copy_decoded(self.h, i, None, 0, ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError(self.L.d4g_last_error().decode())
+        buf = ctypes.create_string_buffer(max(1, n.value))
+        rc = self.L.d4g_batch_copy_decoded(self.h, i, buf, n.value, ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError(self.L.d4g_last_error().decode())
+        return buf.raw[:n.value]
+
+    def stats(self):
+        st = d4g_stats()
+        self.L.d4g_batch_stats(self.h, ctypes.byref(st))
+        return {k: getattr(st, k) for k, _ in d4g_stats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.d4g_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Deft:
+    """Static façade — B/Deft.java."""
+
+    @staticmethod
+    def optimiseDeflateStream(original, mergeBlocks=True):
+        """Returns new bytes iff the stream parses and bits were saved; otherwise the SAME object it was given."""
+        b = Batch([original]).run(mergeBlocks)
+        try:
+            if b.result(0)["status"] == 0:
+                return b.output(0)
+            return original
+        finally:
+            b.close()
+
+    @staticmethod
+    def getSizeBitsFallback(deflateStream):
+        L = _need()
+        bits = ctypes.c_int64()
+        L.d4g_size_bits_fallback.restype = ctypes.c_int
+        L.d4g_size_bits_fallback.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int64)]
+        rc = L.d4g_size_bits_fallback(bytes(deflateStream), len(deflateStream), ctypes.byref(bits))
+        if rc != 0:
+            raise RuntimeError(L.d4g_last_error().decode())
+        return bits.value
+
+
+class DeflateStream:
+    """Object API — B/deflate/DeflateStream.java (parse / optimise / getSizeBits / getUncompressedData / asBytes)."""
+    DEFAULT_NAME = "unnamed stream"
+
+    def __init__(self, name=None):
+        self.name = name or self.DEFAULT_NAME
+        self._data = None
+        self._batch = None
+        self._parsed = None
+
+    def getName(self):
+        return self.name
+
+    def parse(self, data):
+        """-> bool.  Device parse happens on first use; `consumed` gives the bytes DeflateStream.parse(InputStream) reads."""
+        self._data = bytes(data)
+        self.close()
+        probe = Batch([self._data])
+        L = probe.L
+        L.d4g_inflate.restype = ctypes.c_int
+        L.d4g_inflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
+                                  ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_int32)]
+        probe.close()
+        out = ctypes.c_void_p()
+        ol = ctypes.c_size_t()
+        co = ctypes.c_size_t()
+        st = ctypes.c_int32()
+        rc = L.d4g_inflate(self._data, len(self._data), ctypes.byref(out), ctypes.byref(ol), ctypes.byref(co), ctypes.byref(st))
+        if rc != 0:
+            raise RuntimeError(L.d4g_last_error().decode())
+        self.consumed = co.value
+        if st.value < 0:
+            self._parsed = None
+            return False
+        self._parsed = ctypes.string_at(out.value, ol.value)
+        L.d4g_free(out)
+        return True
+
+    def getUncompressedData(self):
+        return self._parsed
+
+    def getSizeBits(self):
+        if self._batch is not None:
+            r = self._batch.result(0)
+            return r["size_bits_in"] - r["saved_bits"]
+        return Deft.getSizeBitsFallback(self._data)
+
+    def optimise(self, mergeBlocks=True):
+        """-> bits saved (DeflateStream.optimise(boolean), :496)."""
+        self.close()
+        self._batch = Batch([self._data]).run(mergeBlocks)
+        return self._batch.result(0)["saved_bits"]
+
+    def asBytes(self):
+        if self._batch is None:
+            self._batch = Batch([self._data]).run(False)
+        return self._batch.output(0)
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+
+class DeflateFilesContainer:
+    """K/DeflateFilesContainer.java:18-43 — the batch seam: independent streams, results in index order."""
+
+    @staticmethod
+    def optimise(streams, mergeBlocks=True, printer=None):
+        """streams: list of raw deflate byte strings.  Returns (total bits saved, [output bytes or the original]).
+        `printer`, when given, receives the transcript lines the reference prints (:31-40)."""
+        b = Batch(streams).run(mergeBlocks)
+        total = 0
+        outs = []
+        try:
+            for i, s in enumerate(streams):
+                r = b.result(i)
+                saved = r["saved_bits"] if r["status"] >= 0 else 0
+                if printer and saved > 0:
+                    printer("%d bits saved in stream %d (%s)" % (saved, i, DeflateStream.DEFAULT_NAME))
+                total += saved
+                outs.append(b.output(i) if r["status"] >= 0 else s)
+            if printer and total > 0:
+                printer("Total bits saved %d" % total)
+        finally:
+            b.close()
+        return total, outs

@@ -1,0 +1,387 @@
+// d4g_device.h — device-side building blocks of the gfx950 optimiser kernels.
+//
+// Everything here is integer work on HBM-resident token arrays with LDS-resident code
+// tables (no MFMA: the path is branchy integer/byte work, HBM/LDS bound).  Each function
+// cites the reference code whose RESULT it reproduces (B/ = deft4j-base/src/main/java/
+// com/github/NeRdTheNed/deft4j/).  The algorithms are re-designed for wave64 execution:
+// token lists are bit masks over the block's token range, header RLE pairs are generated
+// on the fly from code-length runs, and Huffman construction replays the JDK binary heap
+// in LDS so ties break exactly as java.util.PriorityQueue does.
+#pragma once
+#include "d4g_types.h"
+
+#ifndef D4G_HOSTSIM
+#include <hip/hip_runtime.h>
+#endif
+
+#define D4G_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------
+// RFC 1951 symbol arithmetic (B/deflate/Constants.java:9-23,65-128) — closed forms instead
+// of the reference's lookup tables, so no divergent table reads are needed.
+// ---------------------------------------------------------------------------------------
+D4G_DEV int d4g_len2sym(int len, int edge) {
+    if (edge) return 284;                 // Constants.len2litlen edge case (:15-20)
+    if (len == 258) return 285;
+    int x = len - 3;
+    if (x < 8) return 257 + x;
+    int e = (31 - __clz(x)) - 2;
+    return 261 + 4 * e + ((x >> e) & 3);
+}
+D4G_DEV int d4g_lsym_ebits(int s) { return (s < 265 || s == 285) ? 0 : (s - 261) >> 2; }
+D4G_DEV int d4g_lsym_base(int s) {
+    if (s < 265) return s - 254;
+    if (s == 285) return 258;
+    int e = (s - 261) >> 2;
+    return 3 + ((4 + ((s - 261) & 3)) << e);
+}
+D4G_DEV int d4g_dist2sym(int d) {
+    int y = d - 1;
+    if (y < 4) return y;
+    int n = 31 - __clz(y);
+    return 2 * n + ((y >> (n - 1)) & 1);
+}
+D4G_DEV int d4g_dsym_ebits(int s) { return s < 4 ? 0 : (s >> 1) - 1; }
+D4G_DEV int d4g_dsym_base(int s) {
+    if (s < 4) return s + 1;
+    int e = (s >> 1) - 1;
+    return 1 + ((2 + (s & 1)) << e);
+}
+__device__ const uint8_t D4G_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// token word helpers
+D4G_DEV int tok_val(uint32_t a) { return (int)(a & 0x1ffu); }
+D4G_DEV int tok_edge(uint32_t a) { return (int)((a >> 15) & 1u); }
+D4G_DEV int tok_dist(uint32_t a) { return (int)(a >> 16); }
+
+// ---------------------------------------------------------------------------------------
+// wave64 / workgroup reductions
+// ---------------------------------------------------------------------------------------
+D4G_DEV long long wave_sum_i64(long long v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+D4G_DEV long long wave_min_i64(long long v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        long long o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+D4G_DEV int wave_max_i32(int v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        int o = __shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+// Workgroup-wide sum; `red` is an LDS array of >= 17 long long.  All threads call.
+D4G_DEV long long wg_sum_i64(long long v, long long* red) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_i64(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = 0;
+        for (int i = 0; i < nw; i++) s += red[i];
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+D4G_DEV int wg_max_i32(int v, long long* red) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max_i32(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = red[0];
+        for (int i = 1; i < nw; i++) s = red[i] > s ? red[i] : s;
+        red[16] = s;
+    }
+    __syncthreads();
+    return (int)red[16];
+}
+
+// ---------------------------------------------------------------------------------------
+// Huffman tree with exact JDK PriorityQueue tie-breaking and the reference's depth limiter.
+// Reproduces HuffmanTree(freq, limit).getTable().codeLen — B/huffman/HuffmanTree.java:36-128
+// (constructor + limiter), :134-158 (traverse), :164-192 (getTable).  One lane builds one
+// tree; storage is strided so 64 lanes can each build a small tree side by side in LDS.
+//   W = weight type, I = node-index type, MAXN = max leaves.
+//   element i of an array lives at arr[i * stride + lane].
+// ---------------------------------------------------------------------------------------
+template <typename W, typename I, int MAXN>
+struct TreeMem {
+    W* weight;   // [2*MAXN]
+    I* left;     // [2*MAXN]
+    I* right;    // [2*MAXN]
+    I* parent;   // [2*MAXN]  (bit (8*sizeof(I)-1) = side)
+    I* heap;     // [MAXN]
+    I* value;    // [MAXN]   symbol of leaf
+    I* firstAt;  // [MAXN+1] first leaf (DFS order) at each depth
+    I* depth;    // [MAXN]   depth of each leaf
+    static constexpr int NONE = (1 << (8 * sizeof(I) - 1)) - 1;
+    static constexpr int SIDE = 1 << (8 * sizeof(I) - 1);
+    static constexpr size_t bytes(int lanes) {
+        return (size_t)lanes * (sizeof(W) * 2 * MAXN + sizeof(I) * (2 * MAXN * 3 + MAXN * 4 + 1));
+    }
+    __device__ void carve(unsigned char* base, int lanes) {
+        weight = (W*)base; base += sizeof(W) * 2 * MAXN * lanes;
+        left = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
+        right = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
+        parent = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
+        heap = (I*)base; base += sizeof(I) * MAXN * lanes;
+        value = (I*)base; base += sizeof(I) * MAXN * lanes;
+        firstAt = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
+        depth = (I*)base;
+    }
+};
+
+// Returns 0 on success, 1 if the limiter could not rebalance (the reference throws there).
+// freq(i) reads symbol i's frequency; outLen(i, len) receives each symbol's code length.
+template <typename W, typename I, int MAXN, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int numSymbols, int limit, FreqFn freq,
+                              OutFn outLen) {
+    const int NONE = TreeMem<W, I, MAXN>::NONE;
+    const int SIDE = TreeMem<W, I, MAXN>::SIDE;
+#define TM(arr, i) m.arr[(i) * stride + lane]
+    int nl = 0, hs = 0;
+    // java.util.PriorityQueue.offer: append, sift up while key < parent (stop on >=)
+    auto pq_add = [&](int x) {
+        int k = hs++;
+        W wx = TM(weight, x);
+        while (k > 0) {
+            int p = (k - 1) >> 1;
+            int e = TM(heap, p);
+            if (wx >= TM(weight, e)) break;
+            TM(heap, k) = (I)e;
+            k = p;
+        }
+        TM(heap, k) = (I)x;
+    };
+    // PriorityQueue.poll: root out, last element sifts down; left child unless left > right; stop when key <= child
+    auto pq_remove = [&]() -> int {
+        int result = TM(heap, 0);
+        int s = --hs;
+        int x = TM(heap, s);
+        if (s != 0) {
+            W wx = TM(weight, x);
+            int k = 0, half = s >> 1;
+            while (k < half) {
+                int child = 2 * k + 1;
+                int c = TM(heap, child);
+                W wc = TM(weight, c);
+                int r = child + 1;
+                if (r < s) {
+                    int cr = TM(heap, r);
+                    W wr = TM(weight, cr);
+                    if (wc > wr) { c = cr; wc = wr; child = r; }
+                }
+                if (wx <= wc) break;
+                TM(heap, k) = (I)c;
+                k = child;
+            }
+            TM(heap, k) = (I)x;
+        }
+        return result;
+    };
+    for (int i = 0; i < numSymbols; i++) {
+        unsigned f = freq(i);
+        if (f > 0) {
+            TM(weight, nl) = (W)f;
+            TM(value, nl) = (I)i;
+            pq_add(nl);
+            nl++;
+        }
+    }
+    int index = 0;
+    while (hs < 2) {  // dummy leaves — HuffmanTree.java:50-58
+        if (index >= numSymbols || freq(index) == 0) {
+            TM(weight, nl) = (W)1;
+            TM(value, nl) = (I)index;
+            pq_add(nl);
+            nl++;
+        }
+        index++;
+    }
+    int nn = nl;
+    for (int i = 0; i < nl - 1; i++) {
+        int l = pq_remove();
+        int r = pq_remove();
+        int id = nn++;
+        TM(weight, id) = (W)(TM(weight, l) + TM(weight, r));
+        TM(left, id) = (I)l;
+        TM(right, id) = (I)r;
+        TM(parent, l) = (I)id;
+        TM(parent, r) = (I)(id | SIDE);
+        pq_add(id);
+    }
+    int root = pq_remove();
+    int maxDepth = 0;
+    // traverse — DFS, left before right; records each leaf's depth and the first leaf per depth
+    auto traverse = [&]() {
+        for (int d = 0; d <= nl; d++) TM(firstAt, d) = (I)NONE;
+        maxDepth = 0;
+        int node = root, depth = 0;
+        while (true) {
+            while (node >= nl) { node = TM(left, node); depth++; }
+            TM(depth, node) = (I)depth;
+            if (TM(firstAt, depth) == (I)NONE) TM(firstAt, depth) = (I)node;
+            if (depth > maxDepth) maxDepth = depth;
+            while (node != root && (TM(parent, node) & SIDE)) { node = TM(parent, node) & ~SIDE; depth--; }
+            if (node == root) break;
+            node = TM(right, TM(parent, node) & ~SIDE);
+        }
+    };
+    traverse();
+    int err = 0;
+    while (maxDepth > limit) {  // HuffmanTree.java:75-127
+        int leafA = TM(firstAt, maxDepth);
+        int pa = TM(parent, leafA);
+        int p1 = pa & ~SIDE;
+        int leafB = (pa & SIDE) ? TM(left, p1) : TM(right, p1);
+        int pp = TM(parent, p1);
+        int p2 = pp & ~SIDE;
+        if (pp & SIDE) { TM(right, p2) = (I)leafB; TM(parent, leafB) = (I)(p2 | SIDE); }
+        else { TM(left, p2) = (I)leafB; TM(parent, leafB) = (I)p2; }
+        bool moved = false;
+        for (int i = maxDepth - 2; i >= 1; i--) {
+            int leafC = TM(firstAt, i);
+            if (leafC != NONE) {
+                int pc = TM(parent, leafC);
+                int p3 = pc & ~SIDE;
+                int in = p1;  // the detached parent's slot is reused for new InternalNode(leafA, leafC)
+                TM(left, in) = (I)leafA;
+                TM(right, in) = (I)leafC;
+                TM(parent, leafA) = (I)in;
+                TM(parent, leafC) = (I)(in | SIDE);
+                if (pc & SIDE) { TM(right, p3) = (I)in; TM(parent, in) = (I)(p3 | SIDE); }
+                else { TM(left, p3) = (I)in; TM(parent, in) = (I)p3; }
+                moved = true;
+                break;
+            }
+        }
+        if (!moved) { err = 1; break; }
+        traverse();
+    }
+    // getTable: only lengths are needed (codes are canonical by (length, symbol))
+    for (int i = 0; i < nl; i++) {
+        int v = TM(value, i);
+        if (v < numSymbols) outLen(v, (int)TM(depth, i));
+    }
+#undef TM
+    return err;
+}
+
+// ---------------------------------------------------------------------------------------
+// Dynamic-header RLE pairs, generated run by run.
+// HuffmanTable.pack — B/huffman/HuffmanTable.java:70-159.  `emit(sym, run, value)` is called
+// for every pair in output order (run = 0 for a literal code length).
+// flags: bit0 ohh, 1 use8, 2 use7, 3 alt8, 4 noRep, 5 noZRep, 6 noZRep2, 7 noRepZeros
+// ---------------------------------------------------------------------------------------
+#define F_OHH 1
+#define F_USE8 2
+#define F_USE7 4
+#define F_ALT8 8
+#define F_NOREP 16
+#define F_NOZREP 32
+#define F_NOZREP2 64
+#define F_NOREPZEROS 128
+#define F_DEFAULT (F_OHH | F_USE8 | F_USE7)  // DeflateBlockHuffman.rewriteHeader() :480-482
+
+template <typename Emit>
+__device__ void d4g_pack_run(int v, int r, int flags, Emit emit) {
+    if (v == 0) {
+        if (!(flags & F_NOZREP2)) {
+            while (r >= 138) { emit(18, 138, 0); r -= 138; }
+            if (r >= 11) { emit(18, r, 0); r = 0; }
+        }
+        if (!(flags & F_NOZREP)) {
+            while (r >= 10) { emit(17, 10, 0); r -= 10; }
+            if (r >= 3) { emit(17, r, 0); r = 0; }
+        }
+    }
+    if (!(flags & F_NOREP) && r > 0 && (!(flags & F_NOREPZEROS) || v != 0)) {
+        emit(v, 0, v);
+        r--;
+        int j = 6;
+        while (j >= 3) {
+            if (flags & F_OHH) {
+                if ((flags & F_USE8) && r == 8) {
+                    emit(16, (flags & F_ALT8) ? 5 : 4, v);
+                    emit(16, (flags & F_ALT8) ? 3 : 4, v);
+                    r -= 8;
+                    break;
+                }
+                if ((flags & F_USE7) && r == 7) {
+                    emit(16, 4, v);
+                    emit(16, 3, v);
+                    r -= 7;
+                    break;
+                }
+            }
+            if (r - j >= 0) { emit(16, j, v); r -= j; }
+            else j--;
+        }
+    }
+    while (r > 0) { emit(v, 0, v); r--; }
+}
+
+// Runs of the concatenated code lengths (lit then dist; runs may span the boundary — A.4).
+// len(i) reads combined length i.  Calls body(value, runLength) per run.
+template <typename LenFn, typename Body>
+__device__ void d4g_for_runs(int n, LenFn len, Body body) {
+    int last = len(0), run = 1;
+    for (int i = 1; i <= n; i++) {
+        if (i < n && len(i) == last) { run++; }
+        else {
+            body(last, run);
+            if (i < n) { last = len(i); run = 1; }
+        }
+    }
+}
+
+// pair encode/decode (see d4g_types.h)
+D4G_DEV uint16_t pair_encode(int sym, int run, int value) {
+    if (sym < 16) return (uint16_t)sym;
+    if (sym == 16) return (uint16_t)(16 | ((((run - 3) | (value << 2)) & 0xff) << 5));
+    return (uint16_t)(sym | (run << 5));
+}
+D4G_DEV void pair_decode(uint16_t p, int& sym, int& run, int& value) {
+    sym = p & 31;
+    int x = (p >> 5) & 0xff;
+    if (sym < 16) { run = 0; value = sym; }
+    else if (sym == 16) { run = (x & 3) + 3; value = x >> 2; }
+    else { run = x; value = 0; }
+}
+D4G_DEV int pair_extra_bits(int sym) { return sym == 16 ? 2 : sym == 17 ? 3 : 7; }  // getRLEPairSize :133-163
+
+// replaceWithLiteralsIfSmaller on one RLE run pair (DeflateBlockHuffman.java:222-296 with
+// distDec == null): every byte of the run is `value`, so the early-exit loop reduces to one
+// comparison.  Returns bits saved (>= 0) or -1 when the pair stays a run.
+template <typename ClFn>
+D4G_DEV int pair_replace_gain(int sym, int run, int value, bool prune, ClFn cl) {
+    int checkSize = cl(sym) + pair_extra_bits(sym);
+    int b = cl(value);
+    if (b < 1) return -1;
+    int total = run * b;
+    if (prune ? total > checkSize : total >= checkSize) return -1;
+    return checkSize - total;
+}
+
+// removeDynHeaderTrailingZeroLenCodelens — DeflateBlockHuffman.java:335-364 (iterative form)
+template <typename ClFn>
+D4G_DEV int trim_codelens(int nCl, ClFn cl) {
+    while (true) {
+        int lastZero = -1, lastNonZero = nCl;
+        for (int i = 0; i < nCl; i++) {
+            if (cl(D4G_CL_ORDER[i]) == 0) lastZero = i;
+            else lastNonZero = i;
+        }
+        if (lastZero > lastNonZero) nCl = lastZero;
+        else return nCl;
+    }
+}

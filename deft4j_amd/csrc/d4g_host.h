@@ -1,0 +1,775 @@
+// d4g_host.h — host orchestration of libdeft4g: the candidate-search program generator, the
+// stream-level loops of the reference (DeflateStream.optimise / mergeBlocks) and the batch
+// object behind the C ABI.  The host only sequences kernels and resolves the few decisions
+// that depend on a stream-wide bit position (stored-block alignment); all token, Huffman and
+// header arithmetic runs in the HIP kernels.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "d4g_ops.h"
+#include "d4g_parse.h"
+#include "d4g_rt.h"
+#include "d4g_write.h"
+#include "../../include/deft4g.h"
+
+namespace d4g {
+
+typedef long long i64;
+
+// threads per state-op workgroup (the kernels work for any multiple of 64; the CPU emulator
+// in tests/hostsim lowers it to keep fiber switching cheap)
+static inline int state_block() {
+#ifdef D4G_HOSTSIM
+    const char* e = getenv("D4G_SIM_BLOCK");
+    if (e) return atoi(e);
+#endif
+    return 256;
+}
+
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------
+// Candidate-search program = DeflateStream.optimiseBlock (B/deflate/DeflateStream.java:343-490)
+// unrolled into ops over state slots.  Op ids follow the reference's enumeration order, so
+// "first strict minimum" is min over (size, op id, lane).
+// ---------------------------------------------------------------------------------------
+struct Program {
+    std::vector<D4GOp> ops;
+    std::vector<int> opLevel;
+    std::vector<int> slotLevel;
+    int nSlots = 1, nMasks = 1, nLevels = 0;
+    std::vector<std::vector<int>> stateLevels, hdrLevels;
+    D4GOp* dOps = nullptr;
+    int32_t* dLists = nullptr;
+    std::vector<std::pair<size_t, int>> stateOff, hdrOff;
+
+    int new_slot(int level) { slotLevel.push_back(level); return nSlots++; }
+    int emit(int kind, int src, bool hasDst, int arg, bool cand, bool needMask) {
+        D4GOp op;
+        memset(&op, 0, sizeof(op));
+        int level = slotLevel[src] + 1;
+        op.kind = kind;
+        op.src = src;
+        op.dst = hasDst ? new_slot(level) : -1;
+        op.arg = arg;
+        op.seq = cand ? (int)ops.size() : -1;
+        op.maskSlot = needMask ? nMasks++ : -1;
+        op.scratch = -1;
+        op.scratchMask = -1;
+        if (kind == OP_RECODE_FULL) {
+            op.scratch = new_slot(level); new_slot(level);
+            op.scratchMask = nMasks; nMasks += 2;
+        }
+        ops.push_back(op);
+        opLevel.push_back(level);
+        return op.dst;
+    }
+    int OPT(int src, bool requireSaved, bool cand) { return emit(OP_OPT, src, true, requireSaved ? 1 : 0, cand, true); }
+    int RECODE(int src, bool prune, bool cand) { return emit(OP_RECODE, src, true, prune ? 1 : 0, cand, prune); }
+    int FULL(int src, bool cand) { return emit(OP_RECODE_FULL, src, true, 0, cand, true); }
+    int LEAST(int src, int mode) { return emit(OP_LEAST, src, true, mode, false, true); }
+
+    void aor(int t) {  // addOptimisedRecoded — DeflateStream.java:265-317
+        int b1 = OPT(t, false, false);
+        int b2 = OPT(RECODE(t, false, false), false, false);
+        int pruned = RECODE(t, true, false);
+        int b3 = OPT(pruned, false, false);
+        int b4 = OPT(FULL(pruned, false), false, false);
+        emit(OP_HDRSEARCH, b1, false, 0, true, false);
+        emit(OP_HDRSEARCH, b2, false, 0, true, false);
+        emit(OP_HDRSEARCH, b3, false, 0, true, false);
+        emit(OP_HDRSEARCH, b4, false, 0, true, false);
+    }
+    void run(int x) {  // runOptimisationsCallback — :400-442
+        int post = emit(OP_POST, x, true, 0, true, false);
+        OPT(post, true, true);
+        aor(post);
+        int prune = emit(OP_PRUNEHDR, x, true, 0, true, false);
+        OPT(prune, true, true);
+        aor(prune);
+        aor(LEAST(x, 0));
+        aor(LEAST(x, 1));
+    }
+    void multi(int e) {  // runOptimisationsCallbackMulti — :443-463
+        emit(OP_CAND, e, false, 0, true, false);
+        run(e);
+        int hr = RECODE(e, false, true);
+        run(hr);
+        int hp = RECODE(e, true, true);
+        run(hp);
+        int hpf = FULL(hp, true);
+        run(hpf);
+    }
+    void build(bool fixedOrigin) {
+        slotLevel.assign(1, 0);
+        int T = 0;
+        int optimised = OPT(T, true, true);  // op 0: "optimised"; the stored candidate (host) ranks right after it
+        int H, OH;
+        if (fixedOrigin) {
+            H = RECODE(T, false, false);
+            OH = OPT(H, true, false);
+        } else {
+            H = T;
+            OH = optimised;
+        }
+        multi(H);
+        multi(OH);
+        if (!fixedOrigin) emit(OP_TOFIXED_OPT, H, true, 0, true, true);  // "default fixed-huffman"
+        multi(LEAST(H, 0));
+        multi(LEAST(H, 1));
+        nLevels = 0;
+        for (int l : opLevel) nLevels = std::max(nLevels, l + 1);
+        stateLevels.assign(nLevels, {});
+        hdrLevels.assign(nLevels, {});
+        for (size_t i = 0; i < ops.size(); i++)
+            (ops[i].kind == OP_HDRSEARCH ? hdrLevels : stateLevels)[opLevel[i]].push_back((int)i);
+    }
+    void upload() {
+        dOps = (D4GOp*)rt_malloc(ops.size() * sizeof(D4GOp));
+        rt_h2d(dOps, ops.data(), ops.size() * sizeof(D4GOp));
+        std::vector<int32_t> lists;
+        for (int l = 0; l < nLevels; l++) {
+            stateOff.push_back({lists.size(), (int)stateLevels[l].size()});
+            lists.insert(lists.end(), stateLevels[l].begin(), stateLevels[l].end());
+            hdrOff.push_back({lists.size(), (int)hdrLevels[l].size()});
+            lists.insert(lists.end(), hdrLevels[l].begin(), hdrLevels[l].end());
+        }
+        dLists = (int32_t*)rt_malloc(lists.size() * sizeof(int32_t));
+        rt_h2d(dLists, lists.data(), lists.size() * sizeof(int32_t));
+        rt_sync();
+    }
+};
+
+// The 56 (flags, prune) pairs in addOptimisedRecoded's loop order — DeflateStream.java:281-315
+static void build_hdr_tables(uint8_t* flags, uint8_t* prune) {
+    int k = 0;
+    for (int noRepZeros = 0; noRepZeros < 2; noRepZeros++)
+        for (int pr = 0; pr < 2; pr++)
+            for (int noRep = 0; noRep < (noRepZeros ? 1 : 2); noRep++)
+                for (int noZRep = (noRepZeros ? 1 : 0); noZRep < 2; noZRep++)
+                    for (int noZRep2 = 0; noZRep2 < 2; noZRep2++)
+                        for (int ohh = 1; ohh >= 0; ohh--) {
+                            int base = (noRep ? F_NOREP : 0) | (noZRep ? F_NOZREP : 0) | (noZRep2 ? F_NOZREP2 : 0) | (noRepZeros ? F_NOREPZEROS : 0);
+                            if (ohh) {
+                                if (noRep) continue;
+                                for (int use8 = 1; use8 >= 0; use8--)
+                                    for (int use7 = 1; use7 >= 0; use7--) {
+                                        if (!use8 && !use7) continue;
+                                        flags[k] = (uint8_t)(base | F_OHH | (use8 ? F_USE8 : 0) | (use7 ? F_USE7 : 0));
+                                        prune[k] = (uint8_t)pr;
+                                        k++;
+                                    }
+                            } else {
+                                flags[k] = (uint8_t)base;
+                                prune[k] = (uint8_t)pr;
+                                k++;
+                            }
+                        }
+    if (k != 56) throw std::runtime_error("header flag table: expected 56 candidates");
+}
+
+struct Engine {  // per-process device objects shared by all batches
+    Program progDyn, progFixed;
+    uint8_t* dHdrTables = nullptr;  // flags[64] + prune[64]
+    int32_t* dErrors = nullptr;
+    int slotsPerBlock = 0, masksPerBlock = 0, maxOps = 0;
+    bool ready = false;
+    void init() {
+        if (ready) return;
+        progDyn.build(false);
+        progFixed.build(true);
+        progDyn.upload();
+        progFixed.upload();
+        uint8_t tab[128];
+        memset(tab, 0, sizeof(tab));
+        build_hdr_tables(tab, tab + 64);
+        dHdrTables = (uint8_t*)rt_malloc(128);
+        rt_h2d(dHdrTables, tab, 128);
+        dErrors = (int32_t*)rt_malloc(4);
+        rt_memset(dErrors, 0, 4);
+        rt_sync();
+        slotsPerBlock = std::max(progDyn.nSlots, progFixed.nSlots);
+        masksPerBlock = std::max(progDyn.nMasks, progFixed.nMasks);
+        maxOps = (int)std::max(progDyn.ops.size(), progFixed.ops.size());
+        if ((i64)maxOps * 64 >= (1LL << D4G_KEY_SEQ_BITS)) throw std::runtime_error("program too long for the key layout");
+        ready = true;
+    }
+};
+inline Engine& engine() {
+    static Engine e;
+    return e;
+}
+
+// host view of one block of a stream
+struct HBlock {
+    int type = 0;        // current type (a Huffman block may have become STORED)
+    int gpu = -1;        // device block index (Huffman blocks and merge arenas)
+    i64 tokStart = 0, tokCount = 0, uStart = 0, uLen = 0;
+    i64 size = 0;        // Huffman: sizeBits of the current state
+    std::vector<D4GRoundResult> chain;  // phase-1 optimiseBlock rounds
+    i64 size_at(i64 alignment) const {  // getSizeBits(alignment)
+        if (type != D4G_STORED) return size;
+        i64 c = alignment % 8;
+        c = c == 0 ? 0 : 8 - c;
+        return (uLen + 4) * 8 + c;
+    }
+};
+
+struct HStream {
+    int status = 0;
+    std::vector<HBlock> blocks;
+    i64 consumed = 0, sizeBitsIn = 0, saved = 0;
+    i64 inOff = 0, inLen = 0;
+    i64 tokBase = 0, uBase = 0, nTok = 0, nU = 0;
+    i64 outWordBase = 0, outBits = 0;
+    int arena[2] = {-1, -1};
+    // mergeBlocks state machine
+    size_t mIdx = 0;
+    i64 mPos = 0, mSaved = 0;
+    bool mFirst = true, mDone = false, mWaiting = false;
+    int mArenaUsed = -1;
+};
+
+struct Batch {
+    std::vector<std::vector<uint8_t>> inputs;
+    std::vector<HStream> streams;
+    d4g_stats stats;
+    // device
+    uint8_t* dIn = nullptr;
+    uint32_t *dTokA = nullptr, *dTokOff = nullptr;
+    uint8_t* dU = nullptr;
+    D4GBlock* dBlocks = nullptr;
+    D4GState* dStates = nullptr;
+    uint64_t* dMasks = nullptr;
+    long long* dKeys = nullptr;
+    int32_t* dActive = nullptr;
+    D4GRoundResult* dResults = nullptr;
+    uint32_t* dOut = nullptr;
+    std::vector<D4GBlock> hBlocks;  // device block descriptors (host copy)
+    std::vector<int> gpuType;       // current state type per device block
+    i64 outWords = 0;
+    bool ran = false;
+
+    ~Batch() {
+        rt_free(dIn); rt_free(dTokA); rt_free(dTokOff); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut);
+    }
+
+    D4GCtx make_ctx(const Program& P, int nActive) {
+        Engine& E = engine();
+        D4GCtx c;
+        c.tokA = dTokA; c.tokOff = dTokOff; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
+        c.active = dActive; c.errors = E.dErrors; c.nActive = nActive; c.nOps = (int)P.ops.size();
+        c.slotsPerBlock = E.slotsPerBlock; c.masksPerBlock = E.masksPerBlock;
+        return c;
+    }
+
+    void create(size_t n, const uint8_t* const* in, const size_t* len) {
+        memset(&stats, 0, sizeof(stats));
+        double t0 = now_ms();
+        streams.resize(n);
+        i64 off = 0;
+        for (size_t i = 0; i < n; i++) {
+            streams[i].inOff = off;
+            streams[i].inLen = (i64)len[i];
+            off += ((i64)len[i] + 15) & ~15LL;
+            off += 16;
+            stats.bytes_in += (i64)len[i];
+        }
+        i64 total = off + D4G_INCH + 64;
+        dIn = (uint8_t*)rt_malloc((size_t)total);
+        rt_memset(dIn, 0, (size_t)total);
+        for (size_t i = 0; i < n; i++) rt_h2d(dIn + streams[i].inOff, in[i], len[i]);
+        rt_sync();
+        stats.n_streams = (i64)n;
+        stats.ms_upload = now_ms() - t0;
+    }
+
+    // ---- parse (with capacity retry) ----
+    std::vector<D4GStreamOut> pouts;
+    std::vector<D4GParsedBlock> pblocks;
+    std::vector<i64> blkBase, stBase;
+    D4GState* dPStates = nullptr;
+
+    void parse() {
+        size_t n = streams.size();
+        std::vector<D4GStreamIn> ins(n);
+        std::vector<i64> tokCap(n), uCap(n), blkCap(n), stCap(n);
+        for (size_t i = 0; i < n; i++) {
+            i64 L = streams[i].inLen;
+            tokCap[i] = 2 * L + 1024;
+            uCap[i] = 8 * L + 65536;
+            blkCap[i] = L / 64 + 64;
+            stCap[i] = L / 512 + 64;
+        }
+        D4GStreamIn* dIns = (D4GStreamIn*)rt_malloc(n * sizeof(D4GStreamIn));
+        D4GStreamOut* dOuts = (D4GStreamOut*)rt_malloc(n * sizeof(D4GStreamOut));
+        D4GParsedBlock* dPB = nullptr;
+        pouts.resize(n);
+        for (int attempt = 0; attempt < 3; attempt++) {
+            i64 tokTot = 0, uTot = 0, blkTot = 0, stTot = 0;
+            blkBase.assign(n, 0);
+            stBase.assign(n, 0);
+            for (size_t i = 0; i < n; i++) {
+                D4GStreamIn& s = ins[i];
+                s.data = dIn + streams[i].inOff;
+                s.len = streams[i].inLen;
+                s.tokBase = tokTot; s.tokCap = tokCap[i]; tokTot += tokCap[i];
+                s.uBase = uTot; s.uCap = uCap[i]; uTot += (uCap[i] + 15) & ~15LL;
+                s.blkBase = blkTot; s.blkCap = blkCap[i]; blkTot += blkCap[i];
+                s.stBase = stTot; s.stCap = stCap[i]; stTot += stCap[i];
+                streams[i].tokBase = s.tokBase;
+                streams[i].uBase = s.uBase;
+                blkBase[i] = s.blkBase;
+                stBase[i] = s.stBase;
+            }
+            rt_free(dTokA); rt_free(dTokOff); rt_free(dU); rt_free(dPB); rt_free(dPStates);
+            dTokA = (uint32_t*)rt_malloc((size_t)tokTot * 4);
+            dTokOff = (uint32_t*)rt_malloc((size_t)tokTot * 4);
+            dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
+            dPB = (D4GParsedBlock*)rt_malloc((size_t)blkTot * sizeof(D4GParsedBlock));
+            dPStates = (D4GState*)rt_malloc((size_t)stTot * sizeof(D4GState));
+            rt_h2d(dIns, ins.data(), n * sizeof(D4GStreamIn));
+            RT_LAUNCH(k_parse, n, 64, dIns, dOuts, dTokA, dTokOff, dU, dPB, dPStates);
+            stats.kernel_launches++;
+            rt_d2h(pouts.data(), dOuts, n * sizeof(D4GStreamOut));
+            bool retry = false;
+            for (size_t i = 0; i < n; i++) {
+                if (pouts[i].status == 1) {
+                    retry = true;
+                    tokCap[i] = pouts[i].nTok + 16;
+                    uCap[i] = pouts[i].nU + 16;
+                    blkCap[i] = pouts[i].nBlocks + 16;
+                    stCap[i] = pouts[i].nStates + 16;
+                }
+            }
+            if (!retry) {
+                pblocks.resize((size_t)blkTot);
+                rt_d2h(pblocks.data(), dPB, (size_t)blkTot * sizeof(D4GParsedBlock));
+                break;
+            }
+            if (attempt == 2) throw std::runtime_error("parse: capacity retry did not converge");
+        }
+        rt_free(dIns); rt_free(dOuts); rt_free(dPB);
+    }
+
+    // ---- device block table ----
+    void build_blocks(bool merge) {
+        Engine& E = engine();
+        hBlocks.clear();
+        gpuType.clear();
+        std::vector<i64> initState;  // parsed-state index per device block (-1 for arenas)
+        i64 maskWordsTotal = 0;
+        auto add_block = [&](int stream, i64 tokStart, i64 tokCount, i64 uStart, i64 uLen, i64 maskWordsCap, int type) {
+            D4GBlock b;
+            memset(&b, 0, sizeof(b));
+            b.type = type;
+            b.stream = stream;
+            b.tokStart = tokStart;
+            b.tokCount = tokCount;
+            b.uBase = streams[stream].uBase;
+            b.uStart = uStart;
+            b.uLen = uLen;
+            b.stateIdx = (i64)hBlocks.size() * E.slotsPerBlock;
+            b.maskBase = maskWordsTotal;
+            b.maskWords = (tokCount + 63) / 64;
+            maskWordsTotal += maskWordsCap * E.masksPerBlock;
+            hBlocks.push_back(b);
+            gpuType.push_back(type);
+            return (int)hBlocks.size() - 1;
+        };
+        for (size_t si = 0; si < streams.size(); si++) {
+            HStream& s = streams[si];
+            const D4GStreamOut& po = pouts[si];
+            s.status = po.status;
+            s.consumed = po.consumedBytes;
+            s.sizeBitsIn = po.sizeBits;
+            s.nTok = po.nTok;
+            s.nU = po.nU;
+            if (po.status != 0) continue;
+            int nHuff = 0;
+            for (int k = 0; k < po.nBlocks; k++) {
+                const D4GParsedBlock& pb = pblocks[(size_t)blkBase[si] + k];
+                HBlock hb;
+                hb.type = pb.type;
+                hb.tokStart = s.tokBase + pb.tokStart;
+                hb.tokCount = pb.tokCount;
+                hb.uStart = pb.uStart;
+                hb.uLen = pb.uLen;
+                hb.size = pb.sizeBits;
+                if (pb.type != D4G_STORED) {
+                    hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.uStart, hb.uLen, (hb.tokCount + 63) / 64, pb.type);
+                    initState.push_back(stBase[si] + pb.stateIdx);
+                    nHuff++;
+                }
+                s.blocks.push_back(hb);
+                stats.n_blocks++;
+            }
+            stats.n_tokens += po.nTok;
+            stats.bytes_decoded += po.nU;
+            if (merge && nHuff >= 2) {
+                for (int a = 0; a < 2; a++) {
+                    s.arena[a] = add_block((int)si, s.tokBase, 0, 0, 0, (po.nTok + 63) / 64 + 1, D4G_FIXED);
+                    initState.push_back(-1);
+                }
+            }
+        }
+        size_t nb = hBlocks.size();
+        if (nb == 0) return;
+        dBlocks = (D4GBlock*)rt_malloc(nb * sizeof(D4GBlock));
+        rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
+        dStates = (D4GState*)rt_malloc(nb * (size_t)E.slotsPerBlock * sizeof(D4GState));
+        dMasks = (uint64_t*)rt_malloc((size_t)maskWordsTotal * 8 + 64);
+        dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
+        dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
+        dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
+        // slot 0 <- parsed state, mask 0 <- zeros
+        for (size_t b = 0; b < nb; b++) {
+            if (initState[b] >= 0)
+                rt_d2d(dStates + (size_t)hBlocks[b].stateIdx, dPStates + initState[b], sizeof(D4GState));
+            rt_memset(dMasks + hBlocks[b].maskBase, 0, (size_t)hBlocks[b].maskWords * 8);
+        }
+        rt_sync();
+        rt_free(dPStates);
+        dPStates = nullptr;
+    }
+
+    // One optimiseBlock call on every block of `act` (device block indices): runs the program
+    // matching each block's current type and returns the per-block results in `act` order.
+    double msSearch = 0;
+    std::vector<D4GRoundResult> run_round(const std::vector<int>& act) {
+        Engine& E = engine();
+        std::vector<D4GRoundResult> res(act.size());
+        for (int pass = 0; pass < 2; pass++) {
+            const Program& P = pass == 0 ? E.progDyn : E.progFixed;
+            int wantType = pass == 0 ? D4G_DYNAMIC : D4G_FIXED;
+            std::vector<int32_t> sub;
+            std::vector<size_t> subPos;
+            for (size_t i = 0; i < act.size(); i++)
+                if (gpuType[act[i]] == wantType) { sub.push_back(act[i]); subPos.push_back(i); }
+            if (sub.empty()) continue;
+            int nA = (int)sub.size();
+            rt_h2d(dActive, sub.data(), sub.size() * sizeof(int32_t));
+            D4GCtx c = make_ctx(P, nA);
+            RtEvent e0, e1;
+            e0.record();
+            i64 groups = (nA + 7) / 8;
+            for (int l = 0; l < P.nLevels; l++) {
+                if (P.stateOff[l].second) {
+                    i64 grid = 8 * groups * P.stateOff[l].second;
+                    RT_LAUNCH(k_exec_state_ops, grid, state_block(), c, P.dLists + P.stateOff[l].first, P.stateOff[l].second);
+                    stats.kernel_launches++;
+                }
+                if (P.hdrOff[l].second) {
+                    i64 grid = 8 * groups * P.hdrOff[l].second;
+                    RT_LAUNCH(k_exec_hdr_search, grid, 64, c, P.dLists + P.hdrOff[l].first, P.hdrOff[l].second);
+                    stats.kernel_launches++;
+                }
+            }
+            RT_LAUNCH(k_select, nA, state_block(), c, dResults);
+            stats.kernel_launches++;
+            e1.record();
+            std::vector<D4GRoundResult> r(sub.size());
+            rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
+            msSearch += rt_elapsed_ms(e0, e1);
+            for (size_t k = 0; k < sub.size(); k++) {
+                res[subPos[k]] = r[k];
+                gpuType[sub[k]] = r[k].newType;
+            }
+        }
+        stats.rounds++;
+        return res;
+    }
+
+    void check_device_errors() {
+        int32_t e = 0;
+        rt_d2h(&e, engine().dErrors, 4);
+        if (e != 0) {
+            rt_memset(engine().dErrors, 0, 4);
+            rt_sync();
+            throw std::runtime_error("device consistency check failed (" + std::to_string(e) + " errors)");
+        }
+    }
+
+    // Winner of optimiseBlock given the device result and the stream position (stored candidate
+    // = DeflateStream.java:376-383, ranked right after op 0 "optimised").  Returns true when the
+    // stored candidate wins.
+    static bool stored_wins(const D4GRoundResult& r, i64 uLen, i64 pos, i64* storedSize) {
+        if (uLen > 65535) return false;
+        i64 c = pos % 8;
+        c = c == 0 ? 0 : 8 - c;
+        i64 ss = (uLen + 4) * 8 + c;
+        *storedSize = ss;
+        if (ss < r.bestSize) return true;
+        if (ss == r.bestSize && r.improved && r.bestSeq > 0) return true;
+        return false;
+    }
+
+    // ---- DeflateStream.optimise, per-block part — DeflateStream.java:496-566 ----
+    void phase1() {
+        // blocks the reference's loop reaches: it stops right after removing the first empty block
+        std::vector<int> act;
+        std::vector<std::pair<int, int>> owner;  // (stream, block index in stream)
+        for (size_t si = 0; si < streams.size(); si++) {
+            HStream& s = streams[si];
+            if (s.status != 0) continue;
+            for (size_t k = 0; k < s.blocks.size(); k++) {
+                HBlock& b = s.blocks[k];
+                bool sole = (k == 0 && s.blocks.size() == 1);
+                if (b.uLen == 0 && !sole) break;
+                if (b.type != D4G_STORED) { act.push_back(b.gpu); owner.push_back({(int)si, (int)k}); }
+            }
+        }
+        // fixpoint rounds: every block follows its own chain of strictly improving Huffman states
+        while (!act.empty()) {
+            std::vector<D4GRoundResult> res = run_round(act);
+            std::vector<int> nact;
+            std::vector<std::pair<int, int>> nowner;
+            for (size_t i = 0; i < act.size(); i++) {
+                HBlock& b = streams[owner[i].first].blocks[owner[i].second];
+                b.chain.push_back(res[i]);
+                if (res[i].improved) { nact.push_back(act[i]); nowner.push_back(owner[i]); }
+            }
+            act.swap(nact);
+            owner.swap(nowner);
+        }
+        check_device_errors();
+        // sequential resolution with the stream bit position (pos drift included)
+        for (HStream& s : streams) {
+            if (s.status != 0) continue;
+            i64 pos = 0, saved = 0;
+            bool first = true;
+            size_t idx = 0;
+            while (idx < s.blocks.size()) {
+                bool finishPass = true;
+                HBlock& b = s.blocks[idx];
+                bool hasNext = idx + 1 < s.blocks.size();
+                if (b.uLen > 0 || (first && !hasNext)) {
+                    pos += 3;
+                    if (b.type != D4G_STORED) {
+                        size_t step = 0;
+                        // chain index = number of improvements already applied to this block
+                        while (step < b.chain.size() && b.chain[step].curSize != b.size) step++;
+                        if (step >= b.chain.size()) throw std::runtime_error("phase1: chain lookup failed");
+                        const D4GRoundResult& r = b.chain[step];
+                        i64 ss = 0;
+                        if (stored_wins(r, b.uLen, pos, &ss)) {
+                            i64 cs = b.size - ss;
+                            if (cs > 0) { saved += cs; b.type = D4G_STORED; finishPass = false; }
+                        } else if (r.improved) {
+                            saved += b.size - r.bestSize;
+                            b.size = r.bestSize;
+                            finishPass = false;
+                        }
+                    }
+                    pos += b.size_at(pos);
+                } else {
+                    saved += b.size_at(pos + 3) + 3;
+                    s.blocks.erase(s.blocks.begin() + idx);
+                    break;
+                }
+                if (finishPass) { idx++; first = false; }
+            }
+            s.saved = saved;
+            // final Huffman type per block comes from the last round that ran on it
+            for (HBlock& b : s.blocks)
+                if (b.type != D4G_STORED) b.type = gpuType[b.gpu];
+        }
+    }
+
+    // ---- DeflateStream.mergeBlocks — DeflateStream.java:568-650, all streams in lockstep ----
+    struct MergeReq { int stream; int arena; };
+    static bool can_merge(const HBlock& a, const HBlock& b) {
+        if (a.type == D4G_STORED) return a.uLen + b.uLen <= 65535;
+        return b.type == D4G_FIXED || b.type == D4G_DYNAMIC;
+    }
+    // advance a stream's loop until it needs a device evaluation (returns true) or finishes
+    bool merge_advance(int si, MergeReq* req) {
+        HStream& s = streams[si];
+        while (s.mIdx < s.blocks.size()) {
+            HBlock& cur = s.blocks[s.mIdx];
+            bool hasNext = s.mIdx + 1 < s.blocks.size();
+            bool finishPass = true;
+            if (s.mFirst && !hasNext) {
+                s.mPos += cur.size_at(s.mPos + 3) + 3;
+            } else if (cur.uLen > 0) {
+                s.mPos += 3;
+                if (hasNext && can_merge(cur, s.blocks[s.mIdx + 1])) {
+                    HBlock& next = s.blocks[s.mIdx + 1];
+                    if (cur.type == D4G_STORED) {  // DeflateBlockUncompressed.merge — :112-117 (host only)
+                        HBlock m = cur;
+                        m.uLen = cur.uLen + next.uLen;
+                        m.tokCount = 0;
+                        i64 curNo = cur.size_at(s.mPos);
+                        i64 nextNo = next.size_at(s.mPos + curNo + 3);
+                        i64 cs = (curNo + 3 + nextNo) - m.size_at(s.mPos);
+                        if (cs > 0) {
+                            s.mSaved += cs;
+                            s.blocks[s.mIdx] = m;
+                            s.blocks.erase(s.blocks.begin() + s.mIdx + 1);
+                            finishPass = false;
+                        }
+                    } else {
+                        int ar = cur.gpu == s.arena[0] ? s.arena[1] : s.arena[0];
+                        D4GBlock& d = hBlocks[ar];
+                        d.tokStart = cur.tokStart;
+                        d.tokCount = cur.tokCount + next.tokCount;
+                        d.uStart = cur.uStart;
+                        d.uLen = cur.uLen + next.uLen;
+                        d.maskWords = (d.tokCount + 63) / 64;
+                        d.type = D4G_FIXED;
+                        req->stream = si;
+                        req->arena = ar;
+                        s.mWaiting = true;
+                        return true;
+                    }
+                }
+                s.mPos += s.blocks[s.mIdx].size_at(s.mPos);
+            } else {
+                s.mSaved += cur.size_at(s.mPos + 3) + 3;
+                s.blocks.erase(s.blocks.begin() + s.mIdx);
+                break;
+            }
+            if (finishPass) { s.mIdx++; s.mFirst = false; }
+        }
+        s.mDone = true;
+        return false;
+    }
+    void merge_apply(int si, int arena, const D4GRoundResult& r) {
+        HStream& s = streams[si];
+        HBlock& cur = s.blocks[s.mIdx];
+        HBlock& next = s.blocks[s.mIdx + 1];
+        i64 uLen = cur.uLen + next.uLen;
+        i64 curNo = cur.size_at(s.mPos);
+        i64 nextNo = next.size_at(s.mPos + curNo + 3);
+        HBlock m;
+        m.tokStart = cur.tokStart;
+        m.tokCount = cur.tokCount + next.tokCount;
+        m.uStart = cur.uStart;
+        m.uLen = uLen;
+        i64 ss = 0;
+        if (stored_wins(r, uLen, s.mPos, &ss)) { m.type = D4G_STORED; m.gpu = -1; m.size = 0; }
+        else { m.type = r.newType; m.gpu = arena; m.size = r.bestSize; }
+        i64 cs = (curNo + 3 + nextNo) - m.size_at(s.mPos);
+        bool finishPass = true;
+        if (cs > 0) {
+            s.mSaved += cs;
+            s.blocks[s.mIdx] = m;
+            s.blocks.erase(s.blocks.begin() + s.mIdx + 1);
+            finishPass = false;
+        }
+        s.mPos += s.blocks[s.mIdx].size_at(s.mPos);
+        if (finishPass) { s.mIdx++; s.mFirst = false; }
+        s.mWaiting = false;
+    }
+    void phase_merge() {
+        Engine& E = engine();
+        D4GMergeJob* dJobs = (D4GMergeJob*)rt_malloc(streams.size() * sizeof(D4GMergeJob) + 16);
+        while (true) {
+            std::vector<MergeReq> reqs;
+            std::vector<D4GMergeJob> jobs;
+            for (size_t si = 0; si < streams.size(); si++) {
+                HStream& s = streams[si];
+                if (s.status != 0 || s.mDone) continue;
+                MergeReq rq;
+                if (merge_advance((int)si, &rq)) {
+                    reqs.push_back(rq);
+                    D4GMergeJob j;
+                    j.blkA = s.blocks[s.mIdx].gpu;
+                    j.blkB = s.blocks[s.mIdx + 1].gpu;
+                    j.blkM = rq.arena;
+                    j.pad = 0;
+                    jobs.push_back(j);
+                    rt_h2d(dBlocks + rq.arena, &hBlocks[rq.arena], sizeof(D4GBlock));
+                }
+            }
+            if (reqs.empty()) break;
+            rt_h2d(dJobs, jobs.data(), jobs.size() * sizeof(D4GMergeJob));
+            D4GCtx c = make_ctx(E.progFixed, 0);
+            RT_LAUNCH(k_make_merged, jobs.size(), state_block(), c, dJobs);
+            stats.kernel_launches++;
+            std::vector<int> act;
+            for (auto& rq : reqs) { act.push_back(rq.arena); gpuType[rq.arena] = D4G_FIXED; }
+            std::vector<D4GRoundResult> res = run_round(act);
+            for (size_t i = 0; i < reqs.size(); i++) merge_apply(reqs[i].stream, reqs[i].arena, res[i]);
+        }
+        rt_free(dJobs);
+        check_device_errors();
+        for (HStream& s : streams)
+            if (s.status == 0) s.saved += s.mSaved;
+    }
+
+    // ---- DeflateStream.write — :128-145 ----
+    void phase_write() {
+        std::vector<D4GWriteJob> jobs;
+        i64 words = 0;
+        for (HStream& s : streams) {
+            s.outWordBase = words;
+            if (s.status != 0) continue;
+            i64 pos = 0;
+            for (size_t k = 0; k < s.blocks.size(); k++) {
+                const HBlock& b = s.blocks[k];
+                D4GWriteJob j;
+                memset(&j, 0, sizeof(j));
+                j.blk = b.gpu;
+                j.type = b.type;
+                j.isFinal = k + 1 == s.blocks.size();
+                j.bitStart = words * 32 + pos;
+                j.uAbs = s.uBase + b.uStart;
+                j.uLen = b.uLen;
+                jobs.push_back(j);
+                pos += 3;
+                pos += b.size_at(pos);
+            }
+            s.outBits = pos;
+            words += (pos + 31) / 32 + 2;
+        }
+        outWords = words;
+        dOut = (uint32_t*)rt_malloc((size_t)words * 4 + 64);
+        rt_memset(dOut, 0, (size_t)words * 4 + 64);
+        if (!jobs.empty()) {
+            D4GWriteJob* dJobs = (D4GWriteJob*)rt_malloc(jobs.size() * sizeof(D4GWriteJob));
+            rt_h2d(dJobs, jobs.data(), jobs.size() * sizeof(D4GWriteJob));
+            D4GCtx c = make_ctx(engine().progDyn, 0);
+            RT_LAUNCH(k_write, jobs.size(), state_block(), c, dJobs, dOut);
+            stats.kernel_launches++;
+            rt_sync();
+            rt_free(dJobs);
+        }
+        check_device_errors();
+        for (HStream& s : streams)
+            if (s.status == 0) stats.bytes_out += (s.outBits + 7) / 8;
+    }
+
+    void run(bool merge) {
+        if (ran) throw std::runtime_error("batch already ran");
+        ran = true;
+        engine().init();
+        double t0 = now_ms();
+        parse();
+        double t1 = now_ms();
+        build_blocks(merge);
+        phase1();
+        double t2 = now_ms();
+        if (merge) phase_merge();
+        double t3 = now_ms();
+        phase_write();
+        double t4 = now_ms();
+        stats.ms_parse = t1 - t0;
+        stats.ms_optimise = t2 - t1;
+        stats.ms_merge = t3 - t2;
+        stats.ms_write = t4 - t3;
+        stats.ms_total = t4 - t0;
+        stats.ms_search_kernels = msSearch;
+        stats.search_bytes_algorithmic = stats.bytes_in + stats.bytes_decoded + stats.bytes_out;
+    }
+};
+
+}  // namespace d4g

@@ -1,0 +1,679 @@
+// d4g_ops.h — workgroup-cooperative operations on one candidate state held in LDS, and
+// the kernels that execute the candidate-search program.  See d4g_device.h for the pieces.
+#pragma once
+#include "d4g_device.h"
+
+struct D4GCtx {
+    const uint32_t* tokA;
+    const uint32_t* tokOff;
+    const uint8_t* U;
+    const D4GBlock* blocks;
+    D4GState* states;     // [numBlocks * slotsPerBlock]
+    uint64_t* masks;      // mask pools of all blocks
+    long long* keys;      // [numBlocks * nOps] candidate keys of the current round
+    const D4GOp* ops;     // program in the reference's enumeration order (op id = tie-break order)
+    const uint8_t* hdrFlags;  // [56] pack flags of header candidate k  (addOptimisedRecoded loop order)
+    const uint8_t* hdrPrune;  // [56] its `prune` loop variable
+    const int32_t* active;    // [nActive] block indices to run
+    int32_t* errors;          // device error counter
+    int32_t nActive;
+    int32_t nOps;
+    int32_t slotsPerBlock;
+    int32_t masksPerBlock;
+};
+
+// LDS working set of one state-op workgroup
+struct D4GLds {
+    D4GState st;
+    long long red[32];
+    int misc[64];
+    alignas(16) unsigned char treeLit[TreeMem<uint32_t, uint16_t, D4G_NLIT>::bytes(1)];
+    alignas(16) unsigned char treeDist[TreeMem<uint32_t, uint16_t, D4G_NDIST>::bytes(1)];
+    alignas(16) unsigned char treeCl[TreeMem<uint16_t, uint8_t, 20>::bytes(1)];
+    uint16_t clFreq[20];
+};
+
+D4G_DEV uint64_t* mask_ptr(const D4GCtx& c, const D4GBlock& b, int slot) { return c.masks + b.maskBase + (long long)slot * b.maskWords; }
+D4G_DEV D4GState* state_ptr(const D4GCtx& c, int blockIdx_, int slot) { return c.states + ((long long)blockIdx_ * c.slotsPerBlock + slot); }
+
+D4G_DEV void wg_copy_words(uint32_t* dst, const uint32_t* src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+D4G_DEV void wg_load_state(D4GState* S, const D4GState* g) {
+    __syncthreads();
+    wg_copy_words((uint32_t*)S, (const uint32_t*)g, (int)(sizeof(D4GState) / 4));
+    __syncthreads();
+}
+D4G_DEV void wg_store_state(D4GState* g, const D4GState* S) {
+    __syncthreads();
+    wg_copy_words((uint32_t*)g, (const uint32_t*)S, (int)(sizeof(D4GState) / 4));
+    __syncthreads();
+}
+D4G_DEV void wg_copy_mask(uint64_t* dst, const uint64_t* src, long long words) {
+    for (long long i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// Bits of one back-reference under the state's codes — getLitLenSize, DeflateBlockHuffman.java:112-131
+D4G_DEV int backref_cost(const D4GState* S, int len, int edge, int dist, int& lsym, int& dsym) {
+    lsym = d4g_len2sym(len, edge);
+    dsym = d4g_dist2sym(dist);
+    return S->litLen[lsym] + d4g_lsym_ebits(lsym) + S->distLen[dsym] + d4g_dsym_ebits(dsym);
+}
+
+// ---------------------------------------------------------------------------------------
+// replaceBackrefsWithLiteralsIfSmaller — DeflateBlockHuffman.java:312-319 over :222-296.
+// One lane per token, 64 tokens per wave step; the new mask word is the wave ballot.
+// The histogram follows the token list (back-reference symbols out, literal bytes in).
+// ---------------------------------------------------------------------------------------
+__device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
+                                    bool prune) {
+    D4GState* S = &L->st;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    long long saved = 0;
+    __syncthreads();
+    for (long long w = wave; w < b.maskWords; w += nw) {
+        long long t = w * 64 + lane;
+        uint64_t mw = maskIn[w];
+        int bit = (int)((mw >> lane) & 1);
+        if (t < b.tokCount && !bit) {
+            uint32_t a = c.tokA[b.tokStart + t];
+            int dist = tok_dist(a);
+            if (dist > 0) {
+                int len = tok_val(a), lsym, dsym;
+                int cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
+                const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
+                int total = 0;
+                bool ok = true;
+                for (int k = 0; k < len; k++) {
+                    int bs = S->litLen[p[k]];
+                    if (bs < 1) { ok = false; break; }
+                    total += bs;
+                    if (prune ? total > cost : total >= cost) { ok = false; break; }
+                }
+                if (ok) {
+                    bit = 1;
+                    saved += cost - total;
+                    atomicSub(&S->hist[lsym], 1u);
+                    atomicSub(&S->hist[D4G_NLIT + dsym], 1u);
+                    for (int k = 0; k < len; k++) atomicAdd(&S->hist[p[k]], 1u);
+                }
+            }
+        }
+        uint64_t nm = __ballot(bit);
+        if (lane == 0) maskOut[w] = nm;
+    }
+    saved = wg_sum_i64(saved, L->red);
+    if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// removeDistLitLeastExpensive — DeflateBlockHuffman.java:373-458.
+// ---------------------------------------------------------------------------------------
+__device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut, int mode) {
+    D4GState* S = &L->st;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int* binSize = L->misc;        // [32]
+    int* binFreq = L->misc + 32;   // [32]
+    unsigned* flags = (unsigned*)L->red;  // [0] noAllow bits, [1] seen bits, [2] chosen bin + 1
+    __syncthreads();
+    if (threadIdx.x < 64) L->misc[threadIdx.x] = 0;
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+    __syncthreads();
+    if (S->type == D4G_DYNAMIC) {
+        for (long long w = wave; w < b.maskWords; w += nw) {
+            long long t = w * 64 + lane;
+            uint64_t mw = maskIn[w];
+            if (t < b.tokCount && !((mw >> lane) & 1)) {
+                uint32_t a = c.tokA[b.tokStart + t];
+                int dist = tok_dist(a);
+                if (dist > 0) {
+                    int len = tok_val(a), lsym, dsym;
+                    int cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
+                    int bin = lsym - 257;
+                    atomicOr(&flags[1], 1u << bin);
+                    const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
+                    int total = 0;
+                    bool ok = true;
+                    for (int k = 0; k < len; k++) {
+                        int bs = S->litLen[p[k]];
+                        if (bs < 1) { ok = false; break; }
+                        total += bs;
+                    }
+                    if (!ok) atomicOr(&flags[0], 1u << bin);
+                    else { atomicAdd(&binSize[bin], total - cost); atomicAdd(&binFreq[bin], 1); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int rem = -1, remSize = 0, remFreq = 0;
+        for (int i = 0; i < 32; i++) {
+            if (!((flags[0] >> i) & 1) && ((flags[1] >> i) & 1)) {
+                bool doRem = mode == 1 ? binFreq[i] < remFreq : binSize[i] < remSize;
+                if (rem == -1 || doRem) { rem = i; remSize = binSize[i]; remFreq = binFreq[i]; }
+            }
+        }
+        flags[2] = (unsigned)(rem + 1);
+        if (S->type == D4G_DYNAMIC) { S->sizeBits += remSize; S->litlenBits += remSize; }
+    }
+    __syncthreads();
+    int rem = (int)flags[2] - 1;
+    for (long long w = wave; w < b.maskWords; w += nw) {
+        long long t = w * 64 + lane;
+        uint64_t mw = maskIn[w];
+        int bit = (int)((mw >> lane) & 1);
+        if (rem >= 0 && t < b.tokCount && !bit) {
+            uint32_t a = c.tokA[b.tokStart + t];
+            int dist = tok_dist(a);
+            if (dist > 0) {
+                int len = tok_val(a);
+                int lsym = d4g_len2sym(len, tok_edge(a));
+                if (lsym - 257 == rem) {
+                    bit = 1;
+                    const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
+                    atomicSub(&S->hist[lsym], 1u);
+                    atomicSub(&S->hist[D4G_NLIT + d4g_dist2sym(dist)], 1u);
+                    for (int k = 0; k < len; k++) atomicAdd(&S->hist[p[k]], 1u);
+                }
+            }
+        }
+        uint64_t nm = __ballot(bit);
+        if (lane == 0) maskOut[w] = nm;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// Header operations on the LDS state
+// ---------------------------------------------------------------------------------------
+// code-length-code tree from L->clFreq — Huffman.ofRLEPacked, B/huffman/Huffman.java:117-134
+__device__ void t0_build_cl_tree(D4GLds* L) {
+    D4GState* S = &L->st;
+    TreeMem<uint16_t, uint8_t, 20> tm;
+    tm.carve(L->treeCl, 1);
+    for (int i = 0; i < 19; i++) S->clLen[i] = 0;
+    int err = d4g_build_tree(tm, 1, 0, 19, 7, [&](int i) { return (unsigned)L->clFreq[i]; },
+                             [&](int v, int len) { S->clLen[v] = (uint8_t)len; });
+    if (err) S->flags |= 0x100;
+}
+
+// removeTrailingHeaderCodes — DeflateBlockHuffman.java:366-370 (thread 0)
+__device__ void t0_remove_trailing_header_codes(D4GState* S) {
+    if (S->type != D4G_DYNAMIC) return;
+    int n = trim_codelens(S->nCl, [&](int s) { return (int)S->clLen[s]; });
+    long long saved = 3LL * (S->nCl - n);
+    S->nCl = n;
+    S->sizeBits -= saved;
+    S->hdrBits -= saved;
+}
+
+// rewriteHeader — DeflateBlockHuffman.java:484-577.  Thread 0 (the pair list is sequential).
+__device__ void t0_rewrite_header(D4GLds* L, int flags) {
+    D4GState* S = &L->st;
+    if (S->type != D4G_DYNAMIC) return;
+    S->sizeBits -= S->hdrBits;
+    for (int i = 0; i < 19; i++) L->clFreq[i] = 0;
+    int np = 0;
+    int nLit = S->nLit, n = S->nLit + S->nDist;
+    d4g_for_runs(n, [&](int i) { return i < nLit ? (int)S->litLen[i] : (int)S->distLen[i - nLit]; },
+                 [&](int v, int r) {
+                     d4g_pack_run(v, r, flags, [&](int sym, int run, int value) {
+                         S->pairs[np++] = pair_encode(sym, run, value);
+                         L->clFreq[sym]++;
+                     });
+                 });
+    S->nPairs = np;
+    t0_build_cl_tree(L);
+    S->nCl = 19;
+    long long hb = 5 + 5 + 4 + 19 * 3;
+    for (int s = 0; s < 19; s++) hb += (long long)L->clFreq[s] * (S->clLen[s] + (s >= 16 ? pair_extra_bits(s) : 0));
+    S->hdrBits = hb;
+    S->sizeBits += hb;
+#ifdef D4G_HOSTSIM
+    if (getenv("D4G_DEBUG2")) {
+        fprintf(stderr, "rewrite flags %d n %d np %d hb %lld freq:", flags, n, np, hb);
+        for (int s2 = 0; s2 < 19; s2++) fprintf(stderr, " %d/%d", L->clFreq[s2], S->clLen[s2]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    t0_remove_trailing_header_codes(S);
+}
+
+// replaceRLERunsWithLiteralsIfSmaller — DeflateBlockHuffman.java:321-332.  All threads.
+__device__ void wg_replace_rle_runs(D4GLds* L, bool prune) {
+    D4GState* S = &L->st;
+    long long saved = 0;
+    __syncthreads();
+    if (S->type == D4G_DYNAMIC) {
+        for (int i = threadIdx.x; i < S->nPairs; i += blockDim.x) {
+            uint16_t p = S->pairs[i];
+            if ((p & 31) >= 16 && !(p & D4G_PAIR_EXPANDED)) {
+                int sym, run, value;
+                pair_decode(p, sym, run, value);
+                int g = pair_replace_gain(sym, run, value, prune, [&](int s) { return (int)S->clLen[s]; });
+                if (g >= 0) { S->pairs[i] = p | D4G_PAIR_EXPANDED; saved += g; }
+            }
+        }
+    }
+    saved = wg_sum_i64(saved, L->red);
+    if (threadIdx.x == 0) { S->sizeBits -= saved; S->hdrBits -= saved; }
+    __syncthreads();
+}
+
+// recodeHeader — DeflateBlockHuffman.java:579-629 (numCodelenLens deliberately not reset)
+__device__ void wg_recode_header(D4GLds* L) {
+    D4GState* S = &L->st;
+    __syncthreads();
+    if (S->type != D4G_DYNAMIC) return;
+    if (threadIdx.x < 20) L->clFreq[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < S->nPairs; i++) {
+            int sym, run, value;
+            uint16_t p = S->pairs[i];
+            pair_decode(p, sym, run, value);
+            if (p & D4G_PAIR_EXPANDED) L->clFreq[value] += run;
+            else L->clFreq[sym]++;
+        }
+        S->sizeBits -= S->hdrBits;
+        t0_build_cl_tree(L);
+        S->nCl = trim_codelens(S->nCl, [&](int s) { return (int)S->clLen[s]; });
+        long long hb = 5 + 5 + 4 + 3LL * S->nCl;
+        for (int i = 0; i < S->nPairs; i++) {
+            int sym, run, value;
+            uint16_t p = S->pairs[i];
+            pair_decode(p, sym, run, value);
+            if (p & D4G_PAIR_EXPANDED) hb += (long long)run * S->clLen[value];
+            else hb += S->clLen[sym] + (sym >= 16 ? pair_extra_bits(sym) : 0);
+        }
+        S->hdrBits = hb;
+        S->sizeBits += hb;
+    }
+    __syncthreads();
+}
+
+// optimiseHeader — DeflateBlockHuffman.java:471-476
+__device__ void wg_optimise_header(D4GLds* L) {
+    __syncthreads();
+    if (threadIdx.x == 0) t0_remove_trailing_header_codes(&L->st);
+    __syncthreads();
+    wg_replace_rle_runs(L, false);
+}
+
+// Σ token bits from the histogram — recodeToHuffmanInternal, DeflateBlockHuffman.java:759-770
+__device__ void wg_litlen_bits_from_hist(D4GLds* L) {
+    D4GState* S = &L->st;
+    long long v = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) {
+        unsigned h = S->hist[i];
+        if (h) {
+            if (i < D4G_NLIT) v += (long long)h * (S->litLen[i] + (i >= 257 ? d4g_lsym_ebits(i) : 0));
+            else v += (long long)h * (S->distLen[i - D4G_NLIT] + d4g_dsym_ebits(i - D4G_NLIT));
+        }
+    }
+    v = wg_sum_i64(v, L->red);
+    if (threadIdx.x == 0) {
+        S->sizeBits -= S->litlenBits;
+        S->litlenBits = v;
+        S->sizeBits += v;
+    }
+    __syncthreads();
+}
+
+// recodeHuffman — DeflateBlockHuffman.java:670-743 + recodeToHuffman :745-757
+__device__ void wg_recode_huffman(D4GLds* L) {
+    D4GState* S = &L->st;
+    __syncthreads();
+    int ml = 0, md = 0;
+    for (int i = threadIdx.x; i < 286; i += blockDim.x)
+        if (S->hist[i]) ml = i + 1 > ml ? i + 1 : ml;
+    for (int i = threadIdx.x; i < 30; i += blockDim.x)
+        if (S->hist[D4G_NLIT + i]) md = i + 1 > md ? i + 1 : md;
+    int lastLit = wg_max_i32(ml, L->red);
+    int lastDist = wg_max_i32(md, L->red);
+    for (int i = threadIdx.x; i < D4G_NLIT; i += blockDim.x) S->litLen[i] = 0;
+    for (int i = threadIdx.x; i < D4G_NDIST; i += blockDim.x) S->distLen[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TreeMem<uint32_t, uint16_t, D4G_NLIT> tm;
+        tm.carve(L->treeLit, 1);
+        int err = d4g_build_tree(tm, 1, 0, lastLit, 15, [&](int i) { return S->hist[i]; },
+                                 [&](int v, int len) { S->litLen[v] = (uint8_t)len; });
+        if (err) atomicOr((unsigned*)&S->flags, 0x100u);
+        S->nLit = lastLit;
+    }
+    if (threadIdx.x == 64 || (blockDim.x <= 64 && threadIdx.x == 0)) {
+        int nz = 0;
+        for (int i = 0; i < lastDist; i++) nz += S->hist[D4G_NLIT + i] != 0;
+        if (lastDist == 0) {  // handleZero: new HuffmanTable(1)
+            S->nDist = 1;
+        } else if (nz <= 1) {  // handleOne: one used distance code, length 1
+            S->nDist = lastDist;
+            S->distLen[lastDist - 1] = 1;
+        } else {
+            TreeMem<uint32_t, uint16_t, D4G_NDIST> tm;
+            tm.carve(L->treeDist, 1);
+            int err = d4g_build_tree(tm, 1, 0, lastDist, 15, [&](int i) { return S->hist[D4G_NLIT + i]; },
+                                     [&](int v, int len) { S->distLen[v] = (uint8_t)len; });
+            if (err) atomicOr((unsigned*)&S->flags, 0x100u);
+            S->nDist = lastDist;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (S->type != D4G_DYNAMIC) { S->type = D4G_DYNAMIC; S->hdrBits = 0; S->nPairs = 0; S->nCl = 0; }
+    }
+    wg_litlen_bits_from_hist(L);
+    if (threadIdx.x == 0) t0_rewrite_header(L, F_DEFAULT);
+    __syncthreads();
+}
+
+// recodeToFixedHuffman — DeflateBlockHuffman.java:637-653
+__device__ void wg_recode_to_fixed(D4GLds* L) {
+    D4GState* S = &L->st;
+    __syncthreads();
+    if (S->type == D4G_FIXED) return;
+    for (int i = threadIdx.x; i < D4G_NLIT; i += blockDim.x)
+        S->litLen[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 286 ? 8 : 0;  // HuffmanTable.LIT :166-209 (286 codes)
+    for (int i = threadIdx.x; i < D4G_NDIST; i += blockDim.x) S->distLen[i] = i < 30 ? 5 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->sizeBits -= S->hdrBits;
+        S->type = D4G_FIXED;
+        S->hdrBits = 0;
+        S->nLit = S->nDist = S->nCl = S->nPairs = 0;
+    }
+    wg_litlen_bits_from_hist(L);
+}
+
+// ---------------------------------------------------------------------------------------
+// State-op executor: one workgroup = one op of the program on one block.
+// ---------------------------------------------------------------------------------------
+__device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId) {
+    const D4GOp op = c.ops[opId];
+    const D4GBlock b = c.blocks[blk];
+    D4GState* S = &L->st;
+    const D4GState* src = state_ptr(c, blk, op.src);
+    long long* keyp = c.keys + (long long)blk * c.nOps + opId;
+    if (op.kind == OP_CAND) {
+        if (threadIdx.x == 0) *keyp = src->valid ? D4G_MAKE_KEY(src->sizeBits, (long long)opId * 64) : D4G_KEY_NONE;
+        return;
+    }
+    D4GState* dst = state_ptr(c, blk, op.dst);
+    if (!src->valid) {  // the reference never builds this candidate (null / skipped branch)
+        if (threadIdx.x == 0) { dst->valid = 0; *keyp = D4G_KEY_NONE; }
+        return;
+    }
+    wg_load_state(S, src);
+    const uint64_t* maskIn = mask_ptr(c, b, S->maskSlot);
+    switch (op.kind) {
+    case OP_OPT: {
+        long long orig = S->sizeBits;
+        uint64_t* mo = mask_ptr(c, b, op.maskSlot);
+        wg_replace_backrefs(L, c, b, maskIn, mo, false);
+        wg_optimise_header(L);
+        if (threadIdx.x == 0) {
+            S->maskSlot = op.maskSlot;
+            S->valid = (op.arg & 1) ? (orig - S->sizeBits > 0) : 1;
+        }
+        break;
+    }
+    case OP_RECODE: {
+        if (op.arg & 1) {  // recodeHuffmanLessMatches — :655-658
+            uint64_t* mo = mask_ptr(c, b, op.maskSlot);
+            wg_replace_backrefs(L, c, b, maskIn, mo, true);
+            if (threadIdx.x == 0) S->maskSlot = op.maskSlot;
+        }
+        wg_recode_huffman(L);
+        break;
+    }
+    case OP_RECODE_FULL: {  // recodedHuffmanFull — DeflateStream.java:212-229
+        long long prevSize = S->sizeBits;
+        int curSlot = op.src;
+        int same = 1;
+        for (int it = 0;; it++) {
+            int ms = op.scratchMask + (it & 1);
+            const uint64_t* mi = mask_ptr(c, b, S->maskSlot);
+            wg_replace_backrefs(L, c, b, mi, mask_ptr(c, b, ms), true);
+            wg_recode_huffman(L);
+            __syncthreads();
+            long long thisSize = S->sizeBits;
+            __syncthreads();
+            if (thisSize >= prevSize) break;
+            if (threadIdx.x == 0) S->maskSlot = ms;
+            curSlot = op.scratch + (it & 1);
+            wg_store_state(state_ptr(c, blk, curSlot), S);
+            prevSize = thisSize;
+            same = 0;
+        }
+        wg_load_state(S, state_ptr(c, blk, curSlot));
+        wg_copy_mask(mask_ptr(c, b, op.maskSlot), mask_ptr(c, b, S->maskSlot), b.maskWords);
+        if (threadIdx.x == 0) { S->maskSlot = op.maskSlot; S->valid = !same; }
+        break;
+    }
+    case OP_LEAST: {
+        uint64_t* mo = mask_ptr(c, b, op.maskSlot);
+        wg_least(L, c, b, maskIn, mo, op.arg);
+        if (threadIdx.x == 0) S->maskSlot = op.maskSlot;
+        break;
+    }
+    case OP_POST:
+        wg_recode_header(L);
+        break;
+    case OP_PRUNEHDR:
+        wg_replace_rle_runs(L, true);
+        wg_recode_header(L);
+        break;
+    case OP_TOFIXED_OPT: {
+        wg_recode_to_fixed(L);
+        uint64_t* mo = mask_ptr(c, b, op.maskSlot);
+        wg_replace_backrefs(L, c, b, maskIn, mo, false);
+        wg_optimise_header(L);
+        if (threadIdx.x == 0) S->maskSlot = op.maskSlot;
+        break;
+    }
+    default:
+        break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (S->flags & 0x100) {
+#ifdef D4G_HOSTSIM
+            fprintf(stderr, "state op %d kind %d: tree limiter failed\n", opId, op.kind);
+#endif
+            atomicAdd(c.errors, 1);
+        }
+        *keyp = (op.seq >= 0 && S->valid) ? D4G_MAKE_KEY(S->sizeBits, (long long)opId * 64) : D4G_KEY_NONE;
+    }
+    wg_store_state(dst, S);
+}
+
+// XCD-aware (block, op) mapping: workgroups g and g+8 share an XCD (and its L2), so all ops
+// of one deflate block are given workgroup ids that are equal mod 8 — they re-read the same
+// tokens and decoded bytes.  Speed only; nothing depends on placement.
+D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int& blkSlot, int& opRel) {
+    int g = blockIdx.x;
+    int x = g & 7, j = g >> 3;
+    int local = j / nOpsLevel;
+    opRel = j - local * nOpsLevel;
+    blkSlot = local * 8 + x;
+    return blkSlot < nActive;
+}
+
+__global__ void __launch_bounds__(256) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+    __shared__ D4GLds L;
+    int bs, orel;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Header search: the 56 optimiseBlockDynBlock candidates of one base block, one lane each.
+// DeflateStream.java:184-198 (rewriteHeader(flags) -> [recodeHeaderToLessRLEMatches] ->
+// optimiseHeader) enumerated in addOptimisedRecoded's loop order (:281-315).
+// Pairs are never stored: each lane re-generates them from the shared code-length runs and
+// keeps only the 19 symbol counts, two code-length-code tables and its tree scratch in LDS.
+// ---------------------------------------------------------------------------------------
+struct D4GHdrLds {
+    uint8_t runV[D4G_MAXPAIRS];
+    uint16_t runL[D4G_MAXPAIRS];
+    int nRuns;
+    alignas(16) unsigned char tree[TreeMem<uint16_t, uint8_t, 20>::bytes(64)];
+    uint16_t freq[19 * 64];
+    uint8_t cl0[19 * 64];
+    uint8_t cl1[19 * 64];
+};
+
+__device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits) {
+    TreeMem<uint16_t, uint8_t, 20> tm;
+    tm.carve(H->tree, 64);
+#define FQ(s) H->freq[(s) * 64 + lane]
+#define C0(s) H->cl0[(s) * 64 + lane]
+#define C1(s) H->cl1[(s) * 64 + lane]
+    int nRuns = H->nRuns;
+    for (int s = 0; s < 19; s++) { FQ(s) = 0; C0(s) = 0; C1(s) = 0; }
+    // rewriteHeader(flags): symbol counts of the packed lengths
+    for (int r = 0; r < nRuns; r++)
+        d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int, int) { FQ(sym)++; });
+    d4g_build_tree(tm, 64, lane, 19, 7, [&](int i) { return (unsigned)FQ(i); }, [&](int v, int len) { C0(v) = (uint8_t)len; });
+    long long hdr = 5 + 5 + 4 + 19 * 3;
+    for (int s = 0; s < 19; s++) hdr += (long long)FQ(s) * (C0(s) + (s >= 16 ? pair_extra_bits(s) : 0));
+    int nCl = trim_codelens(19, [&](int s) { return (int)C0(s); });
+    hdr -= 3 * (19 - nCl);
+    bool useC1 = false;
+    if (prune) {
+        // recodeHeaderToLessRLEMatches: expand runs that are not shorter than literals, then re-derive the code
+        for (int s = 0; s < 19; s++) FQ(s) = 0;
+        for (int r = 0; r < nRuns; r++)
+            d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int run, int value) {
+                if (sym >= 16 && pair_replace_gain(sym, run, value, true, [&](int s) { return (int)C0(s); }) >= 0) FQ(value) += run;
+                else FQ(sym)++;
+            });
+        d4g_build_tree(tm, 64, lane, 19, 7, [&](int i) { return (unsigned)FQ(i); }, [&](int v, int len) { C1(v) = (uint8_t)len; });
+        nCl = trim_codelens(nCl, [&](int s) { return (int)C1(s); });
+        hdr = 5 + 5 + 4 + 3 * nCl;
+        for (int s = 0; s < 19; s++) hdr += (long long)FQ(s) * (C1(s) + (s >= 16 ? pair_extra_bits(s) : 0));
+        useC1 = true;
+    }
+    // optimiseHeader: trim again, then expand runs that are strictly longer than literals
+    {
+        int n2 = useC1 ? trim_codelens(nCl, [&](int s) { return (int)C1(s); }) : trim_codelens(nCl, [&](int s) { return (int)C0(s); });
+        hdr -= 3 * (nCl - n2);
+        nCl = n2;
+    }
+    long long saved = 0;
+    for (int r = 0; r < nRuns; r++)
+        d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int run, int value) {
+            if (sym < 16) return;
+            if (useC1) {
+                if (pair_replace_gain(sym, run, value, true, [&](int s) { return (int)C0(s); }) >= 0) return;  // already literals
+                int g = pair_replace_gain(sym, run, value, false, [&](int s) { return (int)C1(s); });
+                if (g >= 0) saved += g;
+            } else {
+                int g = pair_replace_gain(sym, run, value, false, [&](int s) { return (int)C0(s); });
+                if (g >= 0) saved += g;
+            }
+        });
+    hdr -= saved;
+#undef FQ
+#undef C0
+#undef C1
+    return litlenBits + hdr;
+}
+
+__global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+    __shared__ D4GHdrLds H;
+    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
+    int bs, orel;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    int blk = c.active[bs];
+    int opId = opList[orel];
+    const D4GOp op = c.ops[opId];
+    const D4GState* base = state_ptr(c, blk, op.src);
+    long long* keyp = c.keys + (long long)blk * c.nOps + opId;
+    int lane = threadIdx.x;
+    if (!base->valid || base->type != D4G_DYNAMIC) {
+        if (lane == 0) *keyp = D4G_KEY_NONE;
+        return;
+    }
+    int nLit = base->nLit, n = base->nLit + base->nDist;
+    for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? base->litLen[i] : base->distLen[i - nLit];
+    __syncthreads();
+    if (lane == 0) {
+        int nr = 0;
+        d4g_for_runs(n, [&](int i) { return (int)comb[i]; }, [&](int v, int r) { H.runV[nr] = (uint8_t)v; H.runL[nr] = (uint16_t)r; nr++; });
+        H.nRuns = nr;
+    }
+    __syncthreads();
+    long long key = D4G_KEY_NONE;
+    if (lane < 56) {
+        long long size = d4g_hdr_candidate(&H, lane, c.hdrFlags[lane], c.hdrPrune[lane], base->litlenBits);
+        key = D4G_MAKE_KEY(size, (long long)opId * 64 + lane);
+    }
+    key = wave_min_i64(key);
+    if (lane == 0) *keyp = key;
+}
+
+// ---------------------------------------------------------------------------------------
+// Selection: first strict minimum over the round's candidates (DeflateStream.java:349-368),
+// winner copied into the block's slot 0.  A header-search winner is materialised by running
+// the reference's own sequence of header operations on its base block.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_select(D4GCtx c, D4GRoundResult* results) {
+    __shared__ D4GLds L;
+    if ((int)blockIdx.x >= c.nActive) return;
+    int blk = c.active[blockIdx.x];
+    const D4GBlock b = c.blocks[blk];
+    D4GState* S = &L.st;
+    D4GState* cur = state_ptr(c, blk, 0);
+    const long long* keys = c.keys + (long long)blk * c.nOps;
+    long long best = D4G_KEY_NONE;
+    for (int i = threadIdx.x; i < c.nOps; i += blockDim.x) best = keys[i] < best ? keys[i] : best;
+    best = wave_min_i64(best);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) L.red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) best = L.red[i] < best ? L.red[i] : best;
+    __syncthreads();
+    long long curSize = cur->sizeBits;
+    long long bestSize = best >> D4G_KEY_SEQ_BITS;
+    int seq = (int)(best & ((1 << D4G_KEY_SEQ_BITS) - 1));
+    bool improved = best != D4G_KEY_NONE && bestSize < curSize;
+    if (improved) {
+        int opId = seq >> 6, lane = seq & 63;
+        const D4GOp op = c.ops[opId];
+        int slot = (op.kind == OP_CAND || op.kind == OP_HDRSEARCH) ? op.src : op.dst;
+        wg_load_state(S, state_ptr(c, blk, slot));
+        if (op.kind == OP_HDRSEARCH) {
+            if (threadIdx.x == 0) t0_rewrite_header(&L, c.hdrFlags[lane]);
+            __syncthreads();
+            if (c.hdrPrune[lane]) { wg_replace_rle_runs(&L, true); wg_recode_header(&L); }
+            wg_optimise_header(&L);
+            if (threadIdx.x == 0 && S->sizeBits != bestSize) {
+#ifdef D4G_HOSTSIM
+                fprintf(stderr, "select: header candidate op %d lane %d materialised to %lld bits (litlen %lld hdr %lld nPairs %d nCl %d nLit %d nDist %d), search said %lld; base size %lld litlen %lld hdr %lld type %d\n", opId, lane, (long long)S->sizeBits, (long long)S->litlenBits, (long long)S->hdrBits, S->nPairs, S->nCl, S->nLit, S->nDist, bestSize,
+                        (long long)state_ptr(c, blk, slot)->sizeBits, (long long)state_ptr(c, blk, slot)->litlenBits, (long long)state_ptr(c, blk, slot)->hdrBits, state_ptr(c, blk, slot)->type);
+#endif
+                atomicAdd(c.errors, 1);
+            }
+        }
+        if (S->maskSlot != 0) wg_copy_mask(mask_ptr(c, b, 0), mask_ptr(c, b, S->maskSlot), b.maskWords);
+        __syncthreads();
+        if (threadIdx.x == 0) { S->maskSlot = 0; S->valid = 1; }
+        wg_store_state(cur, S);
+    }
+    if (threadIdx.x == 0) {
+        D4GRoundResult r;
+        r.curSize = curSize;
+        r.bestSize = improved ? bestSize : curSize;
+        r.bestSeq = improved ? (seq >> 6) : -1;
+        r.improved = improved ? 1 : 0;
+        r.newType = improved ? S->type : cur->type;
+        r.pad = 0;
+        results[blockIdx.x] = r;
+    }
+}

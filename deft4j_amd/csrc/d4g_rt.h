@@ -1,0 +1,61 @@
+// d4g_rt.h — thin runtime layer used by the host orchestration (HIP stream, device memory,
+// kernel launch).  The test-only host simulator (tests/hostsim) provides the same names so the
+// kernels can be debugged and sanitised on a CPU; the product library always uses HIP.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#ifndef D4G_HOSTSIM
+#include <hip/hip_runtime.h>
+
+#define RT_CHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+struct RtGlobals {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    bool ready = false;
+};
+inline RtGlobals& rt() {
+    static RtGlobals g;
+    return g;
+}
+inline void* rt_malloc(size_t n) {
+    void* p = nullptr;
+    RT_CHECK(hipMalloc(&p, n ? n : 16));
+    return p;
+}
+inline void rt_free(void* p) { if (p) (void)hipFree(p); }
+inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream)); }
+inline void rt_d2h(void* h, const void* d, size_t n) {
+    if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream));
+    RT_CHECK(hipStreamSynchronize(rt().stream));
+}
+inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().stream)); }
+inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().stream)); }
+inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().stream)); }
+#define RT_LAUNCH(kern, grid, block, ...)                                                           \
+    do {                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().stream, __VA_ARGS__); \
+        RT_CHECK(hipGetLastError());                                                                \
+    } while (0)
+
+struct RtEvent {
+    hipEvent_t e = nullptr;
+    RtEvent() { RT_CHECK(hipEventCreate(&e)); }
+    ~RtEvent() { if (e) (void)hipEventDestroy(e); }
+    void record() { RT_CHECK(hipEventRecord(e, rt().stream)); }
+};
+inline float rt_elapsed_ms(RtEvent& a, RtEvent& b) {
+    RT_CHECK(hipEventSynchronize(b.e));
+    float ms = 0;
+    RT_CHECK(hipEventElapsedTime(&ms, a.e, b.e));
+    return ms;
+}
+#endif

@@ -1,0 +1,218 @@
+// libdeft4g.hip — the single translation unit of libdeft4g.so (kernels + host + C ABI).
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -o libdeft4g.so libdeft4g.hip
+#include <mutex>
+
+#include "d4g_host.h"
+
+using namespace d4g;
+
+struct d4g_batch {
+    Batch impl;
+};
+
+namespace {
+std::mutex g_mu;  // CompressionUtil calls in from a thread pool (C/CompressionUtil.java:111-117): serialise
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+bool ready() { return rt().ready; }
+}  // namespace
+
+extern "C" {
+
+const char* d4g_last_error(void) { return g_err.c_str(); }
+
+int d4g_init(int device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    try {
+#ifndef D4G_HOSTSIM
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) return fail(D4G_ERR_NODEVICE, "no HIP device available (libdeft4g has no CPU fallback)");
+        if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
+        RT_CHECK(hipSetDevice(device_index));
+        if (!rt().stream) RT_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
+        rt().device = device_index;
+#endif
+        rt().ready = true;
+        engine().init();
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+void d4g_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    rt().ready = false;
+}
+
+d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
+    try {
+        std::unique_ptr<d4g_batch> b(new d4g_batch());
+        b->impl.create(n, in, in_len);
+        return b.release();
+    } catch (const std::exception& ex) {
+        fail(D4G_ERR_RUNTIME, ex.what());
+        return nullptr;
+    }
+}
+
+int d4g_batch_run(d4g_batch* b, int merge_blocks) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    if (!b) return fail(D4G_ERR_ARG, "null batch");
+    try {
+        b->impl.run(merge_blocks != 0);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* saved_bits, size_t* out_len, size_t* consumed,
+                            int64_t* size_bits_in) {
+    if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
+    const HStream& s = b->impl.streams[i];
+    int st = s.status != 0 ? D4G_STREAM_PARSE_ERROR : (s.saved > 0 ? D4G_STREAM_CHANGED : D4G_STREAM_UNCHANGED);
+    if (status) *status = st;
+    if (saved_bits) *saved_bits = s.status == 0 ? s.saved : 0;
+    if (out_len) *out_len = s.status == 0 ? (size_t)((s.outBits + 7) / 8) : 0;
+    if (consumed) *consumed = (size_t)s.consumed;
+    if (size_bits_in) *size_bits_in = s.status == 0 ? s.sizeBitsIn : -1;
+    return D4G_OK;
+}
+
+int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
+    const HStream& s = b->impl.streams[i];
+    if (s.status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
+    size_t n = (size_t)((s.outBits + 7) / 8);
+    if (cap < n) return fail(D4G_ERR_ARG, "output buffer too small");
+    try {
+        rt_d2h(dst, (const uint8_t*)(b->impl.dOut + s.outWordBase), n);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, size_t* len) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
+    const HStream& s = b->impl.streams[i];
+    if (s.status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
+    if (len) *len = (size_t)s.nU;
+    if (!dst) return D4G_OK;
+    if (cap < (size_t)s.nU) return fail(D4G_ERR_ARG, "output buffer too small");
+    try {
+        rt_d2h(dst, b->impl.dU + s.uBase, (size_t)s.nU);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_batch_stats(d4g_batch* b, d4g_stats* st) {
+    if (!b || !st) return fail(D4G_ERR_ARG, "null argument");
+    *st = b->impl.stats;
+    return D4G_OK;
+}
+
+void d4g_batch_destroy(d4g_batch* b) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    delete b;
+}
+
+int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
+                         size_t* out_len, int64_t* saved_bits, int32_t* status) {
+    if (!in || !in_len || !out || !out_len || !status) return fail(D4G_ERR_ARG, "null argument");
+    d4g_batch* b = d4g_batch_create(n, in, in_len);
+    if (!b) return D4G_ERR_RUNTIME;
+    int rc = d4g_batch_run(b, merge_blocks);
+    if (rc == D4G_OK) {
+        for (size_t i = 0; i < n && rc == D4G_OK; i++) {
+            int64_t sv = 0;
+            size_t ol = 0;
+            d4g_batch_stream_result(b, i, &status[i], &sv, &ol, nullptr, nullptr);
+            if (saved_bits) saved_bits[i] = sv;
+            out[i] = nullptr;
+            out_len[i] = 0;
+            if (status[i] == D4G_STREAM_CHANGED) {
+                out[i] = (uint8_t*)malloc(ol ? ol : 1);
+                out_len[i] = ol;
+                rc = d4g_batch_copy_output(b, i, out[i], ol);
+            }
+        }
+    }
+    std::string keep = g_err;
+    d4g_batch_destroy(b);
+    g_err = keep;
+    return rc;
+}
+
+int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
+    if (!in || !bits) return fail(D4G_ERR_ARG, "null argument");
+    const uint8_t* ins[1] = {in};
+    size_t lens[1] = {len};
+    d4g_batch* b = d4g_batch_create(1, ins, lens);
+    if (!b) return D4G_ERR_RUNTIME;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        try {
+            engine().init();
+            b->impl.parse();
+            const D4GStreamOut& o = b->impl.pouts[0];
+            *bits = o.status == 0 ? o.sizeBits : (int64_t)len * 8;  // B/Deft.java:48-54
+            rc = D4G_OK;
+        } catch (const std::exception& ex) {
+            rc = fail(D4G_ERR_RUNTIME, ex.what());
+        }
+    }
+    d4g_batch_destroy(b);
+    return rc;
+}
+
+int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, size_t* consumed, int32_t* status) {
+    if (!in || !out || !out_len || !status) return fail(D4G_ERR_ARG, "null argument");
+    const uint8_t* ins[1] = {in};
+    size_t lens[1] = {len};
+    *out = nullptr;
+    *out_len = 0;
+    d4g_batch* b = d4g_batch_create(1, ins, lens);
+    if (!b) return D4G_ERR_RUNTIME;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        try {
+            engine().init();
+            b->impl.parse();
+            const D4GStreamOut& o = b->impl.pouts[0];
+            if (consumed) *consumed = (size_t)o.consumedBytes;
+            if (o.status != 0) {
+                *status = D4G_STREAM_PARSE_ERROR;
+            } else {
+                *status = D4G_STREAM_UNCHANGED;
+                *out = (uint8_t*)malloc(o.nU ? (size_t)o.nU : 1);
+                *out_len = (size_t)o.nU;
+                rt_d2h(*out, b->impl.dU + b->impl.streams[0].uBase, (size_t)o.nU);
+            }
+            rc = D4G_OK;
+        } catch (const std::exception& ex) {
+            rc = fail(D4G_ERR_RUNTIME, ex.what());
+        }
+    }
+    d4g_batch_destroy(b);
+    return rc;
+}
+
+void d4g_free(void* p) { free(p); }
+
+}  // extern "C"

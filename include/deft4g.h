@@ -1,0 +1,82 @@
+/* deft4g.h — C ABI of libdeft4g.so, the MI355X-native (gfx950, HIP) implementation of
+ * deft4j's DEFLATE stream optimiser hot path.
+ *
+ * Every entry point replaces one seam of the Java reference (paths under /root/reference):
+ *   B/ = deft4j-base/src/main/java/com/github/NeRdTheNed/deft4j/
+ *   K/ = deft4j-container/src/main/java/com/github/NeRdTheNed/deft4j/container/
+ *
+ * Conventions: plain pointers and sizes only; inputs are borrowed for the duration of the
+ * call; buffers returned through `uint8_t**` are allocated by the library and released with
+ * d4g_free().  All functions return 0 on success and a negative value on failure (text in
+ * d4g_last_error()).  Nothing here has a CPU fallback: without a usable HIP device
+ * d4g_init() fails and every other call returns D4G_ERR_NODEVICE.
+ */
+#ifndef DEFT4G_H
+#define DEFT4G_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D4G_OK 0
+#define D4G_ERR_NODEVICE (-1)
+#define D4G_ERR_ARG (-2)
+#define D4G_ERR_RUNTIME (-3)
+
+/* per-stream status, mirroring Deft.optimiseDeflateStream (B/Deft.java:21-34) */
+#define D4G_STREAM_CHANGED 0     /* parse ok and bits saved > 0: use the new bytes            */
+#define D4G_STREAM_UNCHANGED 1   /* parse ok, nothing saved: the caller keeps its ORIGINAL array */
+#define D4G_STREAM_PARSE_ERROR (-1) /* DeflateStream.parse returned false: caller keeps the original */
+
+typedef struct d4g_batch d4g_batch;
+
+typedef struct d4g_stats {
+    double ms_upload, ms_parse, ms_optimise, ms_merge, ms_write, ms_total; /* host wall clock per phase */
+    int64_t n_streams, n_blocks, n_tokens, bytes_in, bytes_decoded, bytes_out;
+    int64_t rounds, kernel_launches;
+    int64_t search_bytes_algorithmic; /* C_in + U + C_out summed over streams */
+    double ms_search_kernels;         /* device time of the candidate-search kernels (HIP events on the library's stream) */
+} d4g_stats;
+
+/* Select the HIP device (one process per GPU) and create the library's stream.
+ * Fails (D4G_ERR_NODEVICE) when no device is usable. */
+int d4g_init(int device_index);
+void d4g_shutdown(void);
+const char* d4g_last_error(void);
+
+/* ---- batch API: K/DeflateFilesContainer.java:18-43 `optimise(List<DeflateStream>, boolean)` ----
+ * Streams are independent.  create() copies the inputs to HBM; run() does all device work
+ * (parse -> optimise -> [mergeBlocks] -> write) with inputs and outputs resident in HBM. */
+d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len);
+int d4g_batch_run(d4g_batch* b, int merge_blocks);
+/* status: D4G_STREAM_*; saved_bits = DeflateStream.optimise(mergeBlocks) (B/deflate/DeflateStream.java:496);
+ * out_len = bytes DeflateStream.asBytes() (:652) would return; consumed = input bytes parse() read
+ * (byte-exact, K/GZFile.java:84 depends on it); size_bits_in = DeflateStream.getSizeBits() (:171) of the input. */
+int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* saved_bits, size_t* out_len,
+                            size_t* consumed, int64_t* size_bits_in);
+/* copy stream i's re-serialised bytes (DeflateStream.write, :128-145) to host memory */
+int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap);
+/* copy stream i's decoded bytes (DeflateStream.getUncompressedData, :159-169) */
+int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, size_t* len);
+int d4g_batch_stats(d4g_batch* b, d4g_stats* st);
+void d4g_batch_destroy(d4g_batch* b);
+
+/* ---- one-shot wrappers ----
+ * Deft.optimiseDeflateStream for n streams: out[i]/out_len[i] are set only when status[i] ==
+ * D4G_STREAM_CHANGED (else out[i] = NULL and the caller returns its original array). */
+int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
+                         size_t* out_len, int64_t* saved_bits, int32_t* status);
+/* Deft.getSizeBitsFallback (B/Deft.java:48-54): parsed bit length, or len*8 when the stream does not parse */
+int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits);
+/* DeflateStream.parse + getUncompressedData; *consumed = bytes read.  Returns D4G_ERR_ARG-style <0 only on
+ * library failure; *status receives D4G_STREAM_PARSE_ERROR for a malformed stream. */
+int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, size_t* consumed, int32_t* status);
+void d4g_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFT4G_H */

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds the TEST-ONLY CPU emulation of the HIP kernels (see hipsim.h).  Optional arg: "san" for ASan/UBSan.
+set -e
+cd "$(dirname "$0")"
+FLAGS="-O2 -g"
+OUT=libdeft4g_hostsim.so
+if [ "$1" = "san" ]; then FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined"; OUT=libdeft4g_hostsim_san.so; fi
+g++ -x c++ -std=c++17 $FLAGS -DD4G_HOSTSIM -include hipsim.h -fPIC -shared -o $OUT hipsim.cpp

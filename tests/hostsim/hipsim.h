@@ -1,0 +1,129 @@
+// hipsim.h — TEST-ONLY single-process SIMT emulator used to debug / sanitise the HIP kernels
+// of deft4j_amd/csrc on a CPU (the build container has no GPU).  It is never part of
+// libdeft4g.so: the product path has no CPU fallback.  Compiled with -DD4G_HOSTSIM, this
+// header stands in for <hip/hip_runtime.h> and d4g_rt.h's HIP half.
+//
+// Model: every workgroup runs as `blockDim.x` ucontext fibers on one OS thread.
+//   __syncthreads()           all live fibers of the workgroup rendezvous
+//   __ballot/__shfl*          all live lanes of a 64-lane wave rendezvous (convergent use only)
+//   atomics                   plain read-modify-write (single OS thread)
+//   __shared__                static storage (workgroups run one after another)
+// It checks convergence (a wave collective met by a workgroup barrier aborts) but cannot see
+// data races; its purpose is functional parity debugging with ASan/UBSan.
+#pragma once
+#include <ucontext.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __constant__ static
+#define __launch_bounds__(...)
+
+struct SimDim3 { unsigned x, y, z; };
+extern SimDim3 threadIdx, blockIdx, blockDim, gridDim;
+struct uint4 { uint32_t x, y, z, w; };
+
+namespace hipsim {
+enum { READY = 0, AT_BARRIER = 1, AT_COLLECTIVE = 2, DONE = 3 };
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    int state = READY;
+    int tid = 0;
+    int parity = 0;
+};
+struct WaveBuf {
+    long long val[2][64];
+    bool arrived[2][64];
+};
+struct Sim {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<WaveBuf> waves;
+    Fiber* cur = nullptr;
+    std::function<void()> body;
+    long long launches = 0;
+    const char* kname = "";
+};
+Sim& sim();
+void yield_to_scheduler();
+void run_grid(unsigned grid, unsigned block, const std::function<void()>& body);
+long long collective(long long v);   // deposits v, waits for the wave, returns this lane's parity buffer index
+}  // namespace hipsim
+
+inline void __syncthreads() {
+    hipsim::sim().cur->state = hipsim::AT_BARRIER;
+    hipsim::yield_to_scheduler();
+}
+inline unsigned long long __ballot(int pred) {
+    int p = (int)hipsim::collective(pred ? 1 : 0);
+    auto& w = hipsim::sim().waves[threadIdx.x >> 6];
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; l++)
+        if (w.arrived[p][l] && w.val[p][l]) m |= 1ULL << l;
+    return m;
+}
+template <typename T>
+inline T __shfl(T v, int src) {
+    long long raw = 0;
+    static_assert(sizeof(T) <= 8, "shfl payload");
+    memcpy(&raw, &v, sizeof(T));
+    int p = (int)hipsim::collective(raw);
+    auto& w = hipsim::sim().waves[threadIdx.x >> 6];
+    src &= 63;
+    if (!w.arrived[p][src]) return v;
+    T out;
+    memcpy(&out, &w.val[p][src], sizeof(T));
+    return out;
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ mask)); }
+template <typename T>
+inline T __shfl_up(T v, int delta) {
+    int lane = threadIdx.x & 63;
+    T o = __shfl(v, lane >= delta ? lane - delta : lane);
+    return o;
+}
+inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+
+template <typename T>
+inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T>
+inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <typename T>
+inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+
+// ---- runtime half (mirrors d4g_rt.h) ----
+struct RtGlobals {
+    void* stream = nullptr;
+    int device = 0;
+    bool ready = false;
+};
+inline RtGlobals& rt() {
+    static RtGlobals g;
+    return g;
+}
+inline void* rt_malloc(size_t n) { return calloc(1, n ? n : 16); }
+inline void rt_free(void* p) { free(p); }
+inline void rt_h2d(void* d, const void* h, size_t n) { if (n) memcpy(d, h, n); }
+inline void rt_d2h(void* h, const void* d, size_t n) { if (n) memcpy(h, d, n); }
+inline void rt_d2d(void* d, const void* s, size_t n) { if (n) memmove(d, s, n); }
+inline void rt_memset(void* d, int v, size_t n) { if (n) memset(d, v, n); }
+inline void rt_sync() {}
+struct RtEvent { void record() {} };
+inline float rt_elapsed_ms(RtEvent&, RtEvent&) { return 0.f; }
+#define RT_CHECK(x) (x)
+#define RT_LAUNCH(kern, grid, block, ...) (hipsim::sim().kname = #kern, hipsim::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kern(__VA_ARGS__); }))
