@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: libdeft4g.so loads, exports every symbol include/deft4g.h
+declares, and refuses to work without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    import deft4j_amd
+    return deft4j_amd.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "deft4g.h")).read()
+    names = sorted(set(re.findall(r"\b(d4g_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 14
+    for n in names:
+        assert getattr(lib, n) is not None, n
+    import deft4j_amd
+    assert sorted(deft4j_amd.EXPORTS) == names
+
+
+def test_no_cpu_fallback_without_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import deft4j_amd
+    rc = lib.d4g_init(0)
+    assert rc < 0
+    assert b"no CPU fallback" in lib.d4g_last_error() or b"device" in lib.d4g_last_error()
+    with pytest.raises(RuntimeError):
+        deft4j_amd.Deft.optimiseDeflateStream(b"\x03\x00")
+    # the raw entry points also refuse
+    arr = (ctypes.c_char_p * 1)(b"\x03\x00")
+    lens = (ctypes.c_size_t * 1)(2)
+    assert not lib.d4g_batch_create(1, arr, lens)
+
+
+def test_product_library_does_not_link_the_oracle():
+    out = os.popen("nm -D --defined-only %s" % os.path.join(ROOT, "deft4j_amd", "libdeft4g.so")).read()
+    assert "oracle_" not in out
+    src = "".join(open(os.path.join(ROOT, "deft4j_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "deft4j_amd", "csrc")))
+    assert "oracle" not in src.lower() or "deft_oracle" not in src
+    py = open(os.path.join(ROOT, "deft4j_amd", "__init__.py")).read() + open(os.path.join(ROOT, "deft4j_amd", "shard.py")).read()
+    assert "oracle" not in py

@@ -1,0 +1,63 @@
+"""Runs the HIP kernels of deft4j_amd/csrc inside the test-only CPU emulator (tests/hostsim) and checks them
+against the golden fixtures and the oracle.  This is how the kernels are debugged and sanitised without a
+GPU; it is not a product path (libdeft4g.so has no CPU fallback — see test_abi.py)."""
+import json
+import os
+import subprocess
+import zlib
+
+import pytest
+
+import oracle_lib as O
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+MAN = {p["stem"]: p for p in json.load(open(os.path.join(G, "manifest.json")))["pairs"]}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    os.environ["D4G_SIM_BLOCK"] = "64"
+    so = os.path.join(ROOT, "tests", "hostsim", "libdeft4g_hostsim.so")
+    subprocess.check_call([os.path.join(ROOT, "tests", "hostsim", "build.sh")])
+    import deft4j_amd as D
+    L = D.load_library(so)
+    D.init(0, lib=L)
+    return D, L
+
+
+def rd(n):
+    return open(os.path.join(G, n), "rb").read()
+
+
+@pytest.mark.parametrize("stem", ["lz-twice-twice.s00", "deflate-store-2.s00", "text.s00", "text.s01", "text.s02", "apng_ball.s12",
+                                  "apng_ball.s09"])
+def test_golden_pairs_in_the_emulator(sim, stem):
+    D, L = sim
+    p = MAN[stem]
+    a = rd(stem + ".in.deflate")
+    b = D.Batch([a], lib=L).run(p["merge_blocks"])
+    r = b.result(0)
+    assert r["saved_bits"] == p["saved_bits"]
+    assert r["consumed"] == len(a)
+    assert b.output(0) == rd(stem + ".out.deflate")
+    assert b.decoded(0) == zlib.decompress(a, -15)
+    b.close()
+
+
+def test_batch_of_synthetic_streams_matches_oracle(sim):
+    D, L = sim
+    t = synth.reptext(6000, 11)
+    c0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+    ins = [synth.make_stream(1500, 3), synth.deflate9(t, zlib.Z_HUFFMAN_ONLY), c0.compress(t[:500]) + c0.flush(),
+           synth.deflate9(b""), b"\x07", synth.deflate9(b"a" * 3000)]
+    for merge in (False, True):
+        b = D.Batch(ins, lib=L).run(merge)
+        for i, a in enumerate(ins):
+            rc, want, saved, consumed, _ = O.optimise(a, merge)
+            r = b.result(i)
+            assert r["status"] == rc, (i, merge)
+            if rc >= 0:
+                assert r["saved_bits"] == saved and b.output(i) == want, (i, merge)
+        b.close()

@@ -1,0 +1,59 @@
+"""world_size-2 `gloo` test of the multi-GPU path (stream sharding + final gather), on CPU.
+The per-rank compute uses the test-only kernel emulator as the stand-in for a GPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+os.environ['D4G_SIM_BLOCK'] = '64'
+import torch, torch.distributed as dist
+import deft4j_amd as D
+from deft4j_amd import shard
+import synth, oracle_lib as O
+rank = int(sys.argv[1]); world = 2
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=world)
+L = D.load_library(os.path.join(%(root)r, 'tests', 'hostsim', 'libdeft4g_hostsim.so'))
+D.init(0, lib=L)
+streams = [synth.make_stream(n, s) for n, s in ((900, 1), (2500, 2), (300, 3), (1800, 4), (1200, 5))] + [b'\x07']
+res = shard.optimise_sharded(streams, False, lambda ss: D.Batch(ss, lib=L), dist=dist)
+if rank == 0:
+    total, outs, saved = res
+    want = [O.optimise(s, False) for s in streams]
+    assert total == sum(max(w[2], 0) for w in want), (total, saved)
+    for s, o, w in zip(streams, outs, want):
+        assert o == (w[1] if w[0] >= 0 else s)
+    print('SHARD_OK', total)
+else:
+    assert res is None
+dist.destroy_process_group()
+"""
+
+
+def test_lpt_partition():
+    sys.path.insert(0, ROOT)
+    from deft4j_amd.shard import lpt_partition
+    sh = lpt_partition([10, 1, 7, 3, 3, 8], 2)
+    assert sorted(sum(sh, [])) == list(range(6))
+    loads = [sum([10, 1, 7, 3, 3, 8][i] for i in s) for s in sh]
+    assert abs(loads[0] - loads[1]) <= 2
+    assert lpt_partition([5], 4) == [[0], [], [], []]
+    assert lpt_partition([], 2) == [[], []]
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    subprocess.check_call([os.path.join(ROOT, "tests", "hostsim", "build.sh")])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    port = 29500 + os.getpid() % 2000
+    code = WORKER % {"root": ROOT, "port": port}
+    f = tmp_path / "w.py"
+    f.write_text(code)
+    procs = [subprocess.Popen([sys.executable, str(f), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARD_OK" in outs[0]
