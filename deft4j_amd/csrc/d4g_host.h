@@ -258,7 +258,7 @@ struct Batch {
 
     ~Batch() {
         rt_free(dIn); rt_free(dTokA); rt_free(dTokOff); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
-        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut);
+        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
@@ -267,7 +267,7 @@ struct Batch {
         c.tokA = dTokA; c.tokOff = dTokOff; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.nActive = nActive; c.nOps = (int)P.ops.size();
-        c.slotsPerBlock = E.slotsPerBlock; c.masksPerBlock = E.masksPerBlock;
+        c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
         return c;
     }
 
@@ -292,81 +292,138 @@ struct Batch {
         stats.ms_upload = now_ms() - t0;
     }
 
-    // ---- parse (with capacity retry) ----
-    std::vector<D4GStreamOut> pouts;
-    std::vector<D4GParsedBlock> pblocks;
-    std::vector<i64> blkBase, stBase;
-    D4GState* dPStates = nullptr;
+    // ---- parse: header scan -> block probes -> chain -> emit -> pointer jumping ----
+    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits; };
+    struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; };
+    std::vector<PStream> ps;
+    D4GStreamDesc* dStreams = nullptr;
+    uint32_t* dSrc = nullptr;
+    int slotsAlloc = 0;
+    double msParseKernels = 0;
 
-    void parse() {
+    // Steps 1-2 + host chain walk: fills `ps` (block list per stream, exact token/byte counts).
+    void parse_probe() {
         size_t n = streams.size();
-        std::vector<D4GStreamIn> ins(n);
-        std::vector<i64> tokCap(n), uCap(n), blkCap(n), stCap(n);
+        ps.assign(n, PStream());
+        std::vector<D4GStreamDesc> sd(n);
+        std::vector<D4GScanTile> tiles;
+        i64 totalBytes = 0;
         for (size_t i = 0; i < n; i++) {
-            i64 L = streams[i].inLen;
-            tokCap[i] = 2 * L + 1024;
-            uCap[i] = 8 * L + 65536;
-            blkCap[i] = L / 64 + 64;
-            stCap[i] = L / 512 + 64;
+            sd[i].data = dIn + streams[i].inOff;
+            sd[i].len = streams[i].inLen;
+            sd[i].uBase = 0;
+            sd[i].uLen = 0;
+            for (i64 b = 0; b < streams[i].inLen; b += D4G_SCAN_TILE) tiles.push_back({(int32_t)i, 0, b});
+            totalBytes += streams[i].inLen;
         }
-        D4GStreamIn* dIns = (D4GStreamIn*)rt_malloc(n * sizeof(D4GStreamIn));
-        D4GStreamOut* dOuts = (D4GStreamOut*)rt_malloc(n * sizeof(D4GStreamOut));
-        D4GParsedBlock* dPB = nullptr;
-        pouts.resize(n);
-        for (int attempt = 0; attempt < 3; attempt++) {
-            i64 tokTot = 0, uTot = 0, blkTot = 0, stTot = 0;
-            blkBase.assign(n, 0);
-            stBase.assign(n, 0);
-            for (size_t i = 0; i < n; i++) {
-                D4GStreamIn& s = ins[i];
-                s.data = dIn + streams[i].inOff;
-                s.len = streams[i].inLen;
-                s.tokBase = tokTot; s.tokCap = tokCap[i]; tokTot += tokCap[i];
-                s.uBase = uTot; s.uCap = uCap[i]; uTot += (uCap[i] + 15) & ~15LL;
-                s.blkBase = blkTot; s.blkCap = blkCap[i]; blkTot += blkCap[i];
-                s.stBase = stTot; s.stCap = stCap[i]; stTot += stCap[i];
-                streams[i].tokBase = s.tokBase;
-                streams[i].uBase = s.uBase;
-                blkBase[i] = s.blkBase;
-                stBase[i] = s.stBase;
+        dStreams = (D4GStreamDesc*)rt_malloc(n * sizeof(D4GStreamDesc));
+        rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
+        RtEvent e0, e1;
+        e0.record();
+        // 1. scan
+        std::vector<D4GProbeIn> cands;
+        std::vector<D4GProbeOut> pout;
+        if (!tiles.empty()) {
+            D4GScanTile* dTiles = (D4GScanTile*)rt_malloc(tiles.size() * sizeof(D4GScanTile));
+            rt_h2d(dTiles, tiles.data(), tiles.size() * sizeof(D4GScanTile));
+            unsigned cap = (unsigned)std::max<i64>(65536, totalBytes / 4);
+            unsigned* dN = (unsigned*)rt_malloc(4);
+            D4GProbeIn* dCands = nullptr;
+            unsigned nc = 0;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                rt_free(dCands);
+                dCands = (D4GProbeIn*)rt_malloc((size_t)cap * sizeof(D4GProbeIn));
+                rt_memset(dN, 0, 4);
+                RT_LAUNCH(k_scan_headers, tiles.size(), 256, dStreams, dTiles, dCands, dN, cap);
+                stats.kernel_launches++;
+                rt_d2h(&nc, dN, 4);
+                if (nc <= cap) break;
+                cap = nc + 1024;
             }
-            rt_free(dTokA); rt_free(dTokOff); rt_free(dU); rt_free(dPB); rt_free(dPStates);
-            dTokA = (uint32_t*)rt_malloc((size_t)tokTot * 4);
-            dTokOff = (uint32_t*)rt_malloc((size_t)tokTot * 4);
-            dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
-            dPB = (D4GParsedBlock*)rt_malloc((size_t)blkTot * sizeof(D4GParsedBlock));
-            dPStates = (D4GState*)rt_malloc((size_t)stTot * sizeof(D4GState));
-            rt_h2d(dIns, ins.data(), n * sizeof(D4GStreamIn));
-            RT_LAUNCH(k_parse, n, 64, dIns, dOuts, dTokA, dTokOff, dU, dPB, dPStates);
-            stats.kernel_launches++;
-            rt_d2h(pouts.data(), dOuts, n * sizeof(D4GStreamOut));
-            bool retry = false;
+            // 2. speculative probes
+            if (nc) {
+                D4GProbeOut* dPo = (D4GProbeOut*)rt_malloc((size_t)nc * sizeof(D4GProbeOut));
+                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, dPo, nc);
+                stats.kernel_launches++;
+                cands.resize(nc);
+                pout.resize(nc);
+                rt_d2h(cands.data(), dCands, (size_t)nc * sizeof(D4GProbeIn));
+                rt_d2h(pout.data(), dPo, (size_t)nc * sizeof(D4GProbeOut));
+                rt_free(dPo);
+            }
+            rt_free(dCands); rt_free(dN); rt_free(dTiles);
+        }
+        stats.scan_candidates = (i64)cands.size();
+        // candidate maps: bit position -> probe result
+        std::vector<std::vector<std::pair<i64, int>>> byStream(n);
+        for (size_t k = 0; k < cands.size(); k++)
+            if (pout[k].status == 0) { byStream[cands[k].stream].push_back({cands[k].bitPos, (int)k}); stats.scan_confirmed++; }
+        for (auto& v : byStream) std::sort(v.begin(), v.end());
+        // chain walk; positions the scan cannot see (fixed / stored / unusual dynamic blocks) are probed exactly
+        std::vector<i64> cur(n, 0), upos(n, 0), spos(n, 0);
+        std::vector<char> done(n, 0);
+        D4GProbeIn* dEx = (D4GProbeIn*)rt_malloc(n * sizeof(D4GProbeIn) + 16);
+        D4GProbeOut* dExOut = (D4GProbeOut*)rt_malloc(n * sizeof(D4GProbeOut) + 16);
+        auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o) {
+            PStream& P = ps[i];
+            if (o.status != 0 || o.needHist > upos[i]) { P.status = -1; done[i] = 1; return; }
+            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits});
+            upos[i] += o.uLen;
+            P.nTok += o.nTok;
+            spos[i] += 3;  // DeflateStream.getSizeBits — :171-182
+            if (o.type == D4G_STORED) {
+                i64 c = spos[i] % 8;
+                c = c == 0 ? 0 : 8 - c;
+                spos[i] += (o.uLen + 4) * 8 + c;
+            } else {
+                spos[i] += o.sizeBits;
+            }
+            cur[i] = o.endBit;
+            if (o.bfinal) { done[i] = 1; P.consumed = (o.endBit + 7) / 8; }
+            else if (o.eofHit) { P.status = -1; done[i] = 1; }  // the next 3-bit read hits EOF
+        };
+        while (true) {
+            std::vector<D4GProbeIn> ex;
+            std::vector<size_t> exStream;
             for (size_t i = 0; i < n; i++) {
-                if (pouts[i].status == 1) {
-                    retry = true;
-                    tokCap[i] = pouts[i].nTok + 16;
-                    uCap[i] = pouts[i].nU + 16;
-                    blkCap[i] = pouts[i].nBlocks + 16;
-                    stCap[i] = pouts[i].nStates + 16;
+                while (!done[i]) {
+                    auto& v = byStream[i];
+                    auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(cur[i], -1));
+                    if (it != v.end() && it->first == cur[i]) accept(i, cur[i], pout[it->second]);
+                    else { ex.push_back({(int32_t)i, 0, cur[i]}); exStream.push_back(i); break; }
                 }
             }
-            if (!retry) {
-                pblocks.resize((size_t)blkTot);
-                rt_d2h(pblocks.data(), dPB, (size_t)blkTot * sizeof(D4GParsedBlock));
-                break;
-            }
-            if (attempt == 2) throw std::runtime_error("parse: capacity retry did not converge");
+            if (ex.empty()) break;
+            rt_h2d(dEx, ex.data(), ex.size() * sizeof(D4GProbeIn));
+            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size());
+            stats.kernel_launches++;
+            stats.exact_probes += (i64)ex.size();
+            std::vector<D4GProbeOut> eo(ex.size());
+            rt_d2h(eo.data(), dExOut, ex.size() * sizeof(D4GProbeOut));
+            for (size_t k = 0; k < ex.size(); k++) accept(exStream[k], ex[k].bitPos, eo[k]);
         }
-        rt_free(dIns); rt_free(dOuts); rt_free(dPB);
+        rt_free(dEx); rt_free(dExOut);
+        e1.record();
+        msParseKernels += rt_elapsed_ms(e0, e1);
+        for (size_t i = 0; i < n; i++) {
+            ps[i].nU = upos[i];
+            ps[i].sizeBits = spos[i];
+            if (ps[i].status != 0) { ps[i].blocks.clear(); ps[i].nTok = 0; ps[i].nU = 0; }
+        }
     }
 
-    // ---- device block table ----
-    void build_blocks(bool merge) {
+    // ---- device block table + steps 3-4 (emit tokens/states, resolve decoded bytes) ----
+    void build_blocks(bool merge, bool needSlots) {
         Engine& E = engine();
+        size_t n = streams.size();
+        slotsAlloc = needSlots ? E.slotsPerBlock : 1;
+        int masksAlloc = needSlots ? E.masksPerBlock : 1;
         hBlocks.clear();
         gpuType.clear();
-        std::vector<i64> initState;  // parsed-state index per device block (-1 for arenas)
-        i64 maskWordsTotal = 0;
+        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0;
+        std::vector<D4GStreamDesc> sd(n);
+        std::vector<D4GEmitIn> emits;
+        std::vector<D4GTokRange> ranges;
         auto add_block = [&](int stream, i64 tokStart, i64 tokCount, i64 uStart, i64 uLen, i64 maskWordsCap, int type) {
             D4GBlock b;
             memset(&b, 0, sizeof(b));
@@ -377,68 +434,130 @@ struct Batch {
             b.uBase = streams[stream].uBase;
             b.uStart = uStart;
             b.uLen = uLen;
-            b.stateIdx = (i64)hBlocks.size() * E.slotsPerBlock;
+            b.stateIdx = (i64)hBlocks.size() * slotsAlloc;
             b.maskBase = maskWordsTotal;
             b.maskWords = (tokCount + 63) / 64;
-            maskWordsTotal += maskWordsCap * E.masksPerBlock;
+            maskWordsTotal += maskWordsCap * masksAlloc;
             hBlocks.push_back(b);
             gpuType.push_back(type);
             return (int)hBlocks.size() - 1;
         };
-        for (size_t si = 0; si < streams.size(); si++) {
+        for (size_t si = 0; si < n; si++) {
             HStream& s = streams[si];
-            const D4GStreamOut& po = pouts[si];
-            s.status = po.status;
-            s.consumed = po.consumedBytes;
-            s.sizeBitsIn = po.sizeBits;
-            s.nTok = po.nTok;
-            s.nU = po.nU;
-            if (po.status != 0) continue;
+            const PStream& P = ps[si];
+            s.status = P.status;
+            s.consumed = P.consumed;
+            s.sizeBitsIn = P.sizeBits;
+            s.nTok = P.nTok;
+            s.nU = P.nU;
+            s.tokBase = tokTot;
+            s.uBase = uTot;
+            sd[si].data = dIn + s.inOff;
+            sd[si].len = s.inLen;
+            sd[si].uBase = uTot;
+            sd[si].uLen = P.nU;
+            tokTot += P.nTok;
+            uTot += (P.nU + 15) & ~15LL;
+            if (P.status != 0) continue;
             int nHuff = 0;
-            for (int k = 0; k < po.nBlocks; k++) {
-                const D4GParsedBlock& pb = pblocks[(size_t)blkBase[si] + k];
+            i64 tpos = 0, upos = 0;
+            for (const PBlock& pb : P.blocks) {
                 HBlock hb;
                 hb.type = pb.type;
-                hb.tokStart = s.tokBase + pb.tokStart;
-                hb.tokCount = pb.tokCount;
-                hb.uStart = pb.uStart;
+                hb.tokStart = s.tokBase + tpos;
+                hb.tokCount = pb.nTok;
+                hb.uStart = upos;
                 hb.uLen = pb.uLen;
                 hb.size = pb.sizeBits;
+                D4GEmitIn em;
+                memset(&em, 0, sizeof(em));
+                em.stream = (int32_t)si;
+                em.type = pb.type;
+                em.bitPos = pb.bitPos;
+                em.tokStart = hb.tokStart;
+                em.uStart = upos;
+                em.uLen = pb.uLen;
+                em.stateIdx = -1;
                 if (pb.type != D4G_STORED) {
                     hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.uStart, hb.uLen, (hb.tokCount + 63) / 64, pb.type);
-                    initState.push_back(stBase[si] + pb.stateIdx);
+                    em.stateIdx = hBlocks[hb.gpu].stateIdx;
                     nHuff++;
                 }
+                emits.push_back(em);
+                ranges.push_back({(int32_t)si, pb.type == D4G_STORED ? 1 : 0, hb.tokStart, hb.tokCount, upos, pb.uLen});
                 s.blocks.push_back(hb);
+                tpos += pb.nTok;
+                upos += pb.uLen;
                 stats.n_blocks++;
             }
-            stats.n_tokens += po.nTok;
-            stats.bytes_decoded += po.nU;
-            if (merge && nHuff >= 2) {
-                for (int a = 0; a < 2; a++) {
-                    s.arena[a] = add_block((int)si, s.tokBase, 0, 0, 0, (po.nTok + 63) / 64 + 1, D4G_FIXED);
-                    initState.push_back(-1);
-                }
+            stats.n_tokens += P.nTok;
+            stats.bytes_decoded += P.nU;
+            if (merge && needSlots && nHuff >= 2) {
+                for (int a = 0; a < 2; a++) s.arena[a] = add_block((int)si, s.tokBase, 0, 0, 0, (P.nTok + 63) / 64 + 1, D4G_FIXED);
             }
         }
         size_t nb = hBlocks.size();
-        if (nb == 0) return;
-        dBlocks = (D4GBlock*)rt_malloc(nb * sizeof(D4GBlock));
-        rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
-        dStates = (D4GState*)rt_malloc(nb * (size_t)E.slotsPerBlock * sizeof(D4GState));
-        dMasks = (uint64_t*)rt_malloc((size_t)maskWordsTotal * 8 + 64);
-        dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
-        dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
-        dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
-        // slot 0 <- parsed state, mask 0 <- zeros
-        for (size_t b = 0; b < nb; b++) {
-            if (initState[b] >= 0)
-                rt_d2d(dStates + (size_t)hBlocks[b].stateIdx, dPStates + initState[b], sizeof(D4GState));
-            rt_memset(dMasks + hBlocks[b].maskBase, 0, (size_t)hBlocks[b].maskWords * 8);
+        rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
+        dTokA = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
+        dTokOff = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
+        dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
+        dSrc = (uint32_t*)rt_malloc((size_t)uTot * 4 + 64);
+        if (nb) {
+            dBlocks = (D4GBlock*)rt_malloc(nb * sizeof(D4GBlock));
+            rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
+            dStates = (D4GState*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(D4GState));
+            dMasks = (uint64_t*)rt_malloc((size_t)maskWordsTotal * 8 + 64);
+            if (needSlots) dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
+            dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
+            dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
+            // mask 0 of every block starts empty (no back-reference expanded)
+            if (needSlots)
+                for (size_t b = 0; b < nb; b++) rt_memset(dMasks + hBlocks[b].maskBase, 0, (size_t)hBlocks[b].maskWords * 8);
         }
+        RtEvent e0, e1;
+        e0.record();
+        if (!emits.empty()) {
+            // 3. emit
+            D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
+            rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
+            D4GParseOut po = {dTokA, dTokOff, dU, dStates};
+            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors);
+            stats.kernel_launches++;
+            // 4. decoded bytes
+            D4GTokRange* dRanges = (D4GTokRange*)rt_malloc(ranges.size() * sizeof(D4GTokRange));
+            rt_h2d(dRanges, ranges.data(), ranges.size() * sizeof(D4GTokRange));
+            int32_t* dBad = (int32_t*)rt_malloc(n * 4 + 16);
+            rt_memset(dBad, 0, n * 4 + 16);
+            const int GF = 8;
+            RT_LAUNCH(k_fill_src, ranges.size() * GF, 256, dStreams, dRanges, dTokA, dTokOff, dU, dSrc, dBad, GF);
+            stats.kernel_launches++;
+            i64 maxU = 0;
+            for (size_t i = 0; i < n; i++) maxU = std::max(maxU, ps[i].nU);
+            int G = (int)std::min<i64>(2048, std::max<i64>(1, (maxU + 4095) / 4096));
+            int32_t* dChanged = (int32_t*)rt_malloc(16);
+            for (int round = 0; round < 40; round++) {
+                rt_memset(dChanged, 0, 4);
+                RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged, G);
+                stats.kernel_launches++;
+                int32_t ch = 0;
+                rt_d2h(&ch, dChanged, 4);
+                stats.jump_rounds++;
+                if (!ch) break;
+            }
+            RT_LAUNCH(k_resolve_streams, n * (size_t)G, 256, dStreams, dSrc, dU, G);
+            stats.kernel_launches++;
+            std::vector<int32_t> bad(n);
+            rt_d2h(bad.data(), dBad, n * 4);
+            for (size_t i = 0; i < n; i++)
+                if (bad[i]) throw std::runtime_error("parse: back-reference before the start of stream (host check missed it)");
+            rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged);
+        }
+        e1.record();
         rt_sync();
-        rt_free(dPStates);
-        dPStates = nullptr;
+        msParseKernels += rt_elapsed_ms(e0, e1);
+        rt_free(dSrc);
+        dSrc = nullptr;
+        check_device_errors();
     }
 
     // One optimiseBlock call on every block of `act` (device block indices): runs the program
@@ -753,9 +872,9 @@ struct Batch {
         ran = true;
         engine().init();
         double t0 = now_ms();
-        parse();
+        parse_probe();
+        build_blocks(merge, true);
         double t1 = now_ms();
-        build_blocks(merge);
         phase1();
         double t2 = now_ms();
         if (merge) phase_merge();
@@ -768,6 +887,7 @@ struct Batch {
         stats.ms_write = t4 - t3;
         stats.ms_total = t4 - t0;
         stats.ms_search_kernels = msSearch;
+        stats.ms_parse_kernels = msParseKernels;
         stats.search_bytes_algorithmic = stats.bytes_in + stats.bytes_decoded + stats.bytes_out;
     }
 };

@@ -1,42 +1,59 @@
-// d4g_parse.h — inflate-to-tokens kernel (one wave per stream).
+// d4g_parse.h — inflate-to-tokens on the GPU, parallel across deflate blocks.
 //
-// Reproduces DeflateStream.parse (B/deflate/DeflateStream.java:72-126),
-// DeflateBlockHuffman.initDynamicDecoder (:892-1010) and decodeStream (:778-890): it emits
-// the token arrays, the decoded bytes, and one initial state per Huffman block (code
-// lengths, header RLE pairs, symbol histogram, bit sizes).  The 32 KiB sliding window lives
-// in a 64 KiB LDS ring so back-reference copies never wait on HBM; the compressed input is
-// staged through an 8 KiB LDS chunk; lane 0 decodes symbols (LUT + canonical fallback with
-// the reference's bit-serial semantics, Huffman.java:170-197), all 64 lanes copy match bytes.
+// Results are those of DeflateStream.parse (B/deflate/DeflateStream.java:72-126),
+// DeflateBlockHuffman.initDynamicDecoder (:892-1010) and decodeStream (:778-890): token arrays,
+// decoded bytes, and one initial state per Huffman block (code lengths, header RLE pairs,
+// symbol histogram, bit sizes).  The reference walks the stream serially; here
+//   1. k_scan_headers     tests EVERY bit position for a plausible dynamic-block header
+//                         (BTYPE, HLIT/HDIST range, complete code-length code) — brute force
+//                         that a 256-CU chip does in well under a millisecond per 10 MB;
+//   2. k_probe_blocks     one wave per candidate decodes the block without output and reports
+//                         where it ends (speculative candidates must also have complete codes);
+//                         the host links candidates into the one chain that starts at bit 0 and
+//                         probes the few positions the scan cannot see (fixed / stored blocks);
+//   3. k_emit_blocks      one wave per confirmed block decodes again, now writing tokens at
+//                         their final offsets and the block's initial state;
+//   4. k_fill_src / k_jump_streams / k_resolve_streams   decoded bytes by pointer jumping: every
+//                         byte points at the byte it copies (src < position), doubling collapses
+//                         the chains onto literals, then one gather fills U.  No 32 KiB window is
+//                         ever walked serially.
+// Decoding itself keeps the reference's semantics (LUT fast path; bit-serial canonical fallback
+// identical to Huffman.readSymbol, B/huffman/Huffman.java:170-197; reads past EOF fail).
 #pragma once
 #include "d4g_device.h"
 
-struct D4GStreamIn {
+struct D4GStreamDesc {
     const uint8_t* data;   // compressed bytes (device, 16-byte aligned, readable 16 KiB past len)
     long long len;
-    long long tokBase;     // this stream's region in tokA/tokOff
-    long long tokCap;
-    long long uBase;       // region in U
-    long long uCap;
-    long long blkBase;     // region in the parsed-block array
-    long long blkCap;
-    long long stBase;      // region in the parsed-state array
-    long long stCap;
+    long long uBase;       // start of this stream's region in U / src
+    long long uLen;
 };
-struct D4GStreamOut {
-    int32_t status;        // 0 ok, -1 parse failure (reference returns false / throws), 1 capacity overflow (retry)
-    int32_t nBlocks;
-    long long nTok, nU, nStates;  // exact needs (valid also on overflow)
-    long long consumedBytes;
-    long long sizeBits;    // DeflateStream.getSizeBits — :171-182
+
+struct D4GProbeIn {
+    int32_t stream;
+    int32_t strict;        // 1: speculative candidate (dynamic only, complete codes required)
+    long long bitPos;
 };
-struct D4GParsedBlock {
+struct D4GProbeOut {
+    int32_t status;        // 0 ok, -1 not a (valid) block
     int32_t type;
-    int32_t stateIdx;      // index into the stream's parsed-state region (-1 for stored)
-    long long tokStart, tokCount, uStart, uLen, sizeBits;
+    int32_t bfinal;
+    int32_t eofHit;        // stored block ran past the end of input (bytes read as 0xff)
+    long long endBit;      // first bit after the block
+    long long nTok, uLen, sizeBits;
+    long long needHist;    // max over back-references of (distance - bytes produced so far in the block)
+};
+struct D4GEmitIn {
+    int32_t stream;
+    int32_t type;
+    long long bitPos;
+    long long tokStart;    // absolute index into tokA/tokOff
+    long long uStart;      // stream-relative offset of the block's decoded bytes
+    long long uLen;
+    long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
 };
 
 #define D4G_LUT_BITS 10
-#define D4G_WIN 65536
 #define D4G_INCH 8192
 
 struct D4GDecTab {          // canonical decoder of one alphabet
@@ -44,35 +61,35 @@ struct D4GDecTab {          // canonical decoder of one alphabet
     uint16_t sorted[D4G_NLIT];        // symbols ordered by (length, index)
     int first[16], count[16], offs[16];
     int useLut;
+    int complete;           // Kraft sum == 1
+    int nCodes;
 };
 
 struct D4GParseLds {
-    uint8_t win[D4G_WIN];
-    uint8_t inbuf[D4G_INCH + 16];
-    D4GDecTab lit, dist, cl;
     D4GState st;
+    D4GDecTab lit, dist, cl;
+    alignas(16) uint8_t inbuf[D4G_INCH + 16];
 };
 
 // Bit reader owned by lane 0 (B/io/BitInputStream.java:59-82: LSB-first).
 struct D4GBitReader {
-    const uint8_t* inbuf;  // LDS chunk
     long long inBase;      // absolute byte index of inbuf[0]
     long long nbits;       // total bits of the stream
     long long pos;         // bits consumed
     uint64_t buf;
     int cnt;
     long long nextByte;    // absolute index of the next byte to load into buf
-    __device__ void reset_to(long long bitpos) {
+    __device__ void reset_to(const uint8_t* inbuf, long long bitpos) {
         pos = bitpos;
         buf = 0;
         cnt = 0;
         nextByte = bitpos >> 3;
-        fill();
+        fill(inbuf);
         int sh = (int)(bitpos & 7);
         buf >>= sh;
         cnt -= sh;
     }
-    __device__ void fill() {
+    __device__ void fill(const uint8_t* inbuf) {
         while (cnt <= 56) {
             long long o = nextByte - inBase;
             uint64_t v = (o >= 0 && o < D4G_INCH + 16) ? inbuf[o] : 0;
@@ -83,6 +100,7 @@ struct D4GBitReader {
     }
     __device__ bool have(int n) const { return pos + n <= nbits; }
     __device__ void skip(int n) { buf >>= n; cnt -= n; pos += n; }
+    __device__ bool near_end() const { return nextByte + 1024 > inBase + D4G_INCH; }
 };
 
 // Huffman.buildCodes (B/huffman/Huffman.java:35-64) + decoder tables.  Lane 0 prepares the
@@ -92,7 +110,8 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
     __syncthreads();
     if (lane == 0) {
         for (int l = 0; l < 16; l++) { T->count[l] = 0; T->first[l] = 0; T->offs[l] = 0; }
-        for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) T->count[lens[i]]++;
+        int nc = 0;
+        for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) { T->count[lens[i]]++; nc++; }
         int next = 0, lastShift = 0, o = 0;
         long long kraft = 0;
         for (int l = 1; l <= 15; l++) {
@@ -107,6 +126,8 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
             }
         }
         T->useLut = kraft <= (1 << 15);
+        T->complete = kraft == (1 << 15);
+        T->nCodes = nc;
         int fill[16];
         for (int l = 0; l < 16; l++) fill[l] = T->offs[l];
         for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) T->sorted[fill[lens[i]]++] = (uint16_t)i;
@@ -129,327 +150,393 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
     __syncthreads();
 }
 
-// Decode one symbol from `bits` (lane 0), `avail` = bits left in the stream.  -1 on failure.
-__device__ int d4g_decode_sym(const D4GDecTab* T, uint64_t bits, long long avail, int* len) {
+// Decode one symbol from `bits` (lane 0), `avail` = bits left in the stream.
+// Returns sym | len << 16, or -1 on failure.  (Packed return instead of an out-pointer: a generic
+// pointer to a private variable next to LDS table reads trips a gfx950 backend assertion in ROCm 7.2.)
+__device__ __forceinline__ int d4g_decode_sym_packed(const D4GDecTab* T, uint64_t bits, long long avail) {
     unsigned e = T->lut[bits & ((1u << D4G_LUT_BITS) - 1)];
     if (e != 0xffff) {
         int l = e >> 9;
         if (l > avail) return -1;
-        *len = l;
-        return e & 511;
+        return (int)(e & 511) | (l << 16);
     }
     int code = 0;
     for (int l = 1; l <= 15; l++) {  // Huffman.readSymbol, bit-serial
         if (l > avail) return -1;
         code = (code << 1) | (int)((bits >> (l - 1)) & 1);
-        if (T->count[l] && code >= T->first[l] && code < T->first[l] + T->count[l]) {
-            *len = l;
-            return T->sorted[T->offs[l] + code - T->first[l]];
-        }
+        if (T->count[l] && code >= T->first[l] && code < T->first[l] + T->count[l])
+            return (int)T->sorted[T->offs[l] + code - T->first[l]] | (l << 16);
     }
     return -1;
 }
+#define D4G_DECODE(T, bits, avail, symVar, lenVar)            \
+    do {                                                      \
+        int _r = d4g_decode_sym_packed(T, bits, avail);       \
+        symVar = _r < 0 ? -1 : (_r & 0xffff);                 \
+        lenVar = _r < 0 ? 0 : (_r >> 16);                     \
+    } while (0)
 
-__global__ void __launch_bounds__(64) k_parse(const D4GStreamIn* ins, D4GStreamOut* outs, uint32_t* tokA, uint32_t* tokOff, uint8_t* U,
-                                              D4GParsedBlock* pblocks, D4GState* pstates) {
+// ---------------------------------------------------------------------------------------
+// 1. Header scan.  One thread per input byte tests its 8 bit positions.
+// ---------------------------------------------------------------------------------------
+struct D4GScanTile { int32_t stream; int32_t pad; long long byteStart; };
+#define D4G_SCAN_TILE 2048
+
+__global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* streams, const D4GScanTile* tiles, D4GProbeIn* cands,
+                                                      unsigned* nCands, unsigned capCands) {
+    __shared__ alignas(16) uint8_t buf[D4G_SCAN_TILE + 32];
+    const D4GScanTile tile = tiles[blockIdx.x];
+    const D4GStreamDesc sd = streams[tile.stream];
+    for (int i = threadIdx.x * 16; i < D4G_SCAN_TILE + 32; i += blockDim.x * 16)
+        *(uint4*)(buf + i) = *(const uint4*)(sd.data + tile.byteStart + i);  // the input buffer is padded past len
+    __syncthreads();
+    long long nbits = sd.len * 8;
+    int lane = threadIdx.x & 63;
+    for (int b = threadIdx.x; b < D4G_SCAN_TILE; b += blockDim.x) {
+        uint64_t lo = 0;   // 96 bits starting at byte b
+        uint32_t hi = 0;
+        for (int k = 0; k < 8; k++) lo |= (uint64_t)buf[b + k] << (8 * k);
+        for (int k = 0; k < 4; k++) hi |= (uint32_t)buf[b + 8 + k] << (8 * k);
+        long long bit0 = (tile.byteStart + b) * 8;
+        for (int s = 0; s < 8; s++) {
+            uint64_t v = s ? ((lo >> s) | ((uint64_t)hi << (64 - s))) : lo;   // window bits 0..63
+            uint64_t w = (v >> 32) | ((uint64_t)(hi >> s) << 32);             // window bits 32..95
+            long long p = bit0 + s;
+            bool ok = ((v >> 1) & 3) == 2 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+            int ncl = (int)((v >> 13) & 15) + 4;
+            ok = ok && (p + 17 + 3 * ncl <= nbits);
+            if (ok) {
+                // the code-length code must be complete: sum 2^(7-l) == 128, at least two codes
+                int kraft = 0, used = 0;
+                for (int i = 0; i < ncl; i++) {
+                    int bitIdx = 17 + 3 * i;
+                    int l = bitIdx + 3 <= 64 ? (int)((v >> bitIdx) & 7) : (int)((w >> (bitIdx - 32)) & 7);
+                    if (l) { kraft += 128 >> l; used++; }
+                }
+                ok = kraft == 128 && used >= 2;
+            }
+            unsigned long long m = __ballot(ok);
+            if (m) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(nCands, (unsigned)__popcll(m));
+                base = __shfl(base, 0);
+                if (ok) {
+                    unsigned idx = base + (unsigned)__popcll(m & ((1ULL << lane) - 1));
+                    if (idx < capCands) { D4GProbeIn c; c.stream = tile.stream; c.strict = 1; c.bitPos = p; cands[idx] = c; }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2./3. Block parser: one wave per block.  EMIT = false probes (counts, end position),
+// EMIT = true writes tokens and the block's initial state.
+// ---------------------------------------------------------------------------------------
+struct D4GParseOut {
+    uint32_t* tokA;
+    uint32_t* tokOff;
+    uint8_t* U;
+    D4GState* states;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long long bitPos, int strict, D4GProbeOut& po,
+                                const D4GEmitIn* em, const D4GParseOut& out) {
     __shared__ D4GParseLds L;
-    const D4GStreamIn in = ins[blockIdx.x];
     int lane = threadIdx.x & 63;
     D4GBitReader br;
-    br.inbuf = L.inbuf;
     br.inBase = 0;
-    br.nbits = in.len * 8;
+    br.nbits = sd.len * 8;
     br.pos = 0; br.buf = 0; br.cnt = 0; br.nextByte = 0;
-    long long nTok = 0, nU = 0, nStates = 0, streamBits = 0;
-    int nBlocks = 0;
-    int status = 0;
     D4GState* S = &L.st;
-    bool fin = false;
-    // stage the first input chunk
-    auto stage = [&](long long base) {
+    auto stage = [&](long long bitpos) {
+        long long base = (bitpos >> 3) & ~15LL;
+        if (base > sd.len) base = sd.len & ~15LL;
         __syncthreads();
-        for (int i = lane * 16; i < D4G_INCH + 16; i += 64 * 16) {
-            const uint4* g = (const uint4*)(in.data + base + i);
-            *(uint4*)(L.inbuf + i) = *g;
-        }
+        for (int i = lane * 16; i < D4G_INCH + 16; i += 64 * 16) *(uint4*)(L.inbuf + i) = *(const uint4*)(sd.data + base + i);
         __syncthreads();
+        br.inBase = base;
+        if (lane == 0) br.reset_to(L.inbuf, bitpos);
     };
-    stage(0);
-    if (lane == 0) br.reset_to(0);
-    // refill when lane 0's reader is within 1 KiB of the chunk end (decided wave-uniformly)
-    auto maybe_refill = [&]() {
-        long long nb = __shfl((long long)br.nextByte, 0);
-        long long base = __shfl((long long)br.inBase, 0);
-        if (nb + 1024 > base + D4G_INCH && base + D4G_INCH < in.len + 16) {
-            long long bitpos = __shfl((long long)br.pos, 0);
-            long long nbase = (bitpos >> 3) & ~15LL;
-            stage(nbase);
-            br.inBase = nbase;
-            if (lane == 0) br.reset_to(bitpos);
-        }
-    };
-    while (!fin && status == 0) {
-        maybe_refill();
-        // ---- block prolog ----
-        long long pk = 0;
+    po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
+    stage(bitPos);
+    long long pk = 0;
+    if (lane == 0) {
+        if (!br.have(3)) pk = -1;
+        else { pk = (long long)(br.buf & 7); br.skip(3); }
+    }
+    pk = __shfl(pk, 0);
+    if (pk < 0) return;
+    po.bfinal = (int)(pk & 1);
+    int btype = (int)(pk >> 1);
+    po.type = btype;
+    if (btype == 3) return;
+    if (strict && btype != 2) return;
+    if (btype == 0) {
+        // DeflateBlockUncompressed.parse — B/deflate/DeflateBlockUncompressed.java:23-36
+        long long r = 0, p = 0;
         if (lane == 0) {
-            if (!br.have(3)) pk = -1;
-            else { br.fill(); pk = (long long)(br.buf & 7); br.skip(3); }
-        }
-        pk = __shfl(pk, 0);
-        if (pk < 0) { status = -1; break; }
-        fin = (pk & 1) != 0;
-        int btype = (int)(pk >> 1);
-        if (btype == 3) { status = -1; break; }
-        long long blkTok0 = nTok, blkU0 = nU;
-        long long blkSize = 0;
-        int stateIdx = -1;
-        if (btype == 0) {
-            // DeflateBlockUncompressed.parse — B/deflate/DeflateBlockUncompressed.java:23-36
-            long long r = 0;
-            if (lane == 0) {
-                long long p = (br.pos + 7) & ~7LL;
-                if (p + 32 > br.nbits) r = -1;
-                else {
-                    br.reset_to(p);
-                    int len = (int)(br.buf & 0xffff), nlen = (int)((br.buf >> 16) & 0xffff);
-                    if (nlen != ((~len) & 0xffff)) r = -1;
-                    else r = len;
-                    br.skip(32);
-                }
+            p = (br.pos + 7) & ~7LL;
+            if (p + 32 > br.nbits) r = -1;
+            else {
+                br.reset_to(L.inbuf, p);
+                int len = (int)(br.buf & 0xffff), nlen = (int)((br.buf >> 16) & 0xffff);
+                r = nlen != ((~len) & 0xffff) ? -1 : len;
             }
-            r = __shfl(r, 0);
-            if (r < 0) { status = -1; break; }
-            int len = (int)r;
-            long long bytePos = __shfl((long long)br.pos, 0) >> 3;
+        }
+        r = __shfl(r, 0);
+        p = __shfl(p, 0);
+        if (r < 0) return;
+        int len = (int)r;
+        long long bytePos = (p + 32) >> 3;
+        if (EMIT) {
             for (int k = lane; k < len; k += 64) {
                 // bytes past the end of input read as (byte)-1 in the reference (BitInputStreamUtil.readFromBIS)
-                uint8_t v = (bytePos + k < in.len) ? in.data[bytePos + k] : 0xff;
-                L.win[(nU + k) & (D4G_WIN - 1)] = v;
-                if (nU + k < in.uCap) U[in.uBase + nU + k] = v;
+                uint8_t v = (bytePos + k < sd.len) ? sd.data[bytePos + k] : 0xff;
+                out.U[sd.uBase + em->uStart + k] = v;
             }
-            long long np = (bytePos + len) * 8;
-            if (np > br.nbits) np = br.nbits + 8;  // EOF was hit: every later read fails
-            // re-stage the input at the new position
-            {
-                long long nbase = np > br.nbits ? (br.nbits >> 3) & ~15LL : (np >> 3) & ~15LL;
-                stage(nbase);
-                br.inBase = nbase;
-                if (lane == 0) { br.reset_to(np > br.nbits ? br.nbits : np); br.pos = np; }
-            }
-            nU += len;
-            blkSize = 0;  // stored size depends on bit position (host computes it)
-        } else {
-            for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)S)[i] = 0;
-            __syncthreads();
-            if (btype == 1) {
-                for (int i = lane; i < D4G_NLIT; i += 64) S->litLen[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 286 ? 8 : 0;
-                for (int i = lane; i < D4G_NDIST; i += 64) S->distLen[i] = i < 30 ? 5 : 0;
-                if (lane == 0) S->type = D4G_FIXED;
-                __syncthreads();
-            } else {
-                // initDynamicDecoder — DeflateBlockHuffman.java:892-1010
-                long long r = 0;
-                if (lane == 0) {
-                    if (!br.have(14)) r = -1;
-                    else {
-                        br.fill();
-                        S->nLit = (int)(br.buf & 31) + 257;
-                        S->nDist = (int)((br.buf >> 5) & 31) + 1;
-                        S->nCl = (int)((br.buf >> 10) & 15) + 4;
-                        br.skip(14);
-                        if (S->nLit > 288) r = -1;
-                        if (r == 0 && !br.have(3 * S->nCl)) r = -1;
-                        if (r == 0) {
-                            for (int i = 0; i < S->nCl; i++) {
-                                br.fill();
-                                S->clLen[D4G_CL_ORDER[i]] = (uint8_t)(br.buf & 7);
-                                br.skip(3);
-                            }
-                        }
-                        S->type = D4G_DYNAMIC;
-                        S->hdrBits = 5 + 5 + 4 + 3 * S->nCl;
-                    }
-                }
-                r = __shfl(r, 0);
-                if (r < 0) { status = -1; break; }
-                d4g_build_decoder(&L.cl, S->clLen, 19);
-                if (lane == 0) {
-                    int i = 0, np = 0;
-                    int combined = S->nLit + S->nDist;
-                    while (i < combined && r == 0) {
-                        br.fill();
-                        int cl = 0;
-                        int sym = d4g_decode_sym(&L.cl, br.buf, br.nbits - br.pos, &cl);
-                        if (sym < 0 || sym > 18) { r = -1; break; }
-                        br.skip(cl);
-                        S->hdrBits += cl;
-                        int run = 0, value = sym;
-                        if (sym == 16) {
-                            if (i < 1 || !br.have(2)) { r = -1; break; }
-                            run = (int)(br.buf & 3) + 3;
-                            br.skip(2); S->hdrBits += 2;
-                            value = (i - 1 < S->nLit) ? S->litLen[i - 1] : S->distLen[i - 1 - S->nLit];
-                        } else if (sym == 17) {
-                            if (!br.have(3)) { r = -1; break; }
-                            run = (int)(br.buf & 7) + 3;
-                            br.skip(3); S->hdrBits += 3;
-                            value = 0;
-                        } else if (sym == 18) {
-                            if (!br.have(7)) { r = -1; break; }
-                            run = (int)(br.buf & 127) + 11;
-                            br.skip(7); S->hdrBits += 7;
-                            value = 0;
-                        }
-                        int cnt = run ? run : 1;
-                        if (i + cnt > combined) { r = -1; break; }
-                        for (int k = 0; k < cnt; k++, i++) {
-                            if (i < S->nLit) S->litLen[i] = (uint8_t)value;
-                            else S->distLen[i - S->nLit] = (uint8_t)value;
-                        }
-                        S->pairs[np++] = pair_encode(sym, run, value);
-                    }
-                    S->nPairs = np;
-                }
-                r = __shfl(r, 0);
-                if (r < 0) { status = -1; break; }
-            }
-            // The fixed code (HuffmanTable.LIT, B/huffman/HuffmanTable.java:166-209) is the RFC 1951 code over
-            // 288 symbols; 286/287 take code space but are not decodable symbols (decodeStream rejects > 285).
-            if (btype == 1 && lane == 0) { S->litLen[286] = 8; S->litLen[287] = 8; }
-            d4g_build_decoder(&L.lit, S->litLen, btype == 1 ? 288 : S->nLit);
-            if (btype == 1 && lane == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
-            d4g_build_decoder(&L.dist, S->distLen, btype == 1 ? 30 : S->nDist);
-            // ---- decodeStream — DeflateBlockHuffman.java:778-890 ----
-            long long litlenBits = 0;
-            while (true) {
-                maybe_refill();
-                // packed result: bit0 fail, bit1 eob, bits 8.. val (9 bits), bits 20.. dist (16 bits)
-                long long res = 0;
-                if (lane == 0) {
-                    br.fill();
-                    uint64_t bits = br.buf;
-                    long long avail = br.nbits - br.pos;
-                    int cl = 0, val = 0, dist = 0, edge = 0, used = 0;
-                    bool ok = true;
-                    int sym = d4g_decode_sym(&L.lit, bits, avail, &cl);
-                    if (sym < 0 || sym > 285) ok = false;
-                    else if (sym <= 256) { val = sym; used = cl; S->hist[sym]++; }
-                    else {
-                        int eb = d4g_lsym_ebits(sym);
-                        int len = d4g_lsym_base(sym);
-                        used = cl + eb;
-                        if (used > avail) ok = false;
-                        else {
-                            len += (int)((bits >> cl) & ((1u << eb) - 1));
-                            edge = (len == 258 && sym == 284);
-                            int dcl = 0;
-                            int ds = d4g_decode_sym(&L.dist, bits >> used, avail - used, &dcl);
-                            if (ds < 0 || ds > 29) ok = false;
-                            else {
-                                int deb = d4g_dsym_ebits(ds);
-                                if (used + dcl + deb > avail) ok = false;
-                                else {
-                                    dist = d4g_dsym_base(ds) + (int)((bits >> (used + dcl)) & ((1u << deb) - 1));
-                                    used += dcl + deb;
-                                    if (dist > nU) ok = false;  // reference: walks off the first block (NullPointerException)
-                                    S->hist[sym]++;
-                                    S->hist[D4G_NLIT + ds]++;
-                                    val = len;
-                                }
-                            }
-                        }
-                    }
-                    if (ok) {
-                        br.skip(used);
-                        litlenBits += used;
-                        if (nTok < in.tokCap) {
-                            tokA[in.tokBase + nTok] = (uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16);
-                            tokOff[in.tokBase + nTok] = (uint32_t)nU;
-                        }
-                        res = ((long long)(sym == 256) << 1) | ((long long)val << 8) | ((long long)dist << 20);
-                    } else {
-#ifdef D4G_HOSTSIM
-                        if (getenv("D4G_DEBUG")) fprintf(stderr, "parse fail: tok %lld nU %lld pos %lld sym %d val %d dist %d used %d avail %lld cl %d\n", nTok, nU, br.pos, sym, val, dist, used, avail, cl);
-#endif
-                        res = 1;
-                    }
-                }
-                res = __shfl(res, 0);
-                if (res & 1) { status = -1; break; }
-                nTok++;
-                if (res & 2) break;
-                int val = (int)((res >> 8) & 0x1ff), dist = (int)(res >> 20);
-                if (dist == 0) {
-                    if (lane == 0) {
-                        L.win[nU & (D4G_WIN - 1)] = (uint8_t)val;
-                        if (nU < in.uCap) U[in.uBase + nU] = (uint8_t)val;
-                    }
-                    nU++;
-                } else {
-                    // overlapping copies are periodic in `dist`: byte k = window[nU - dist + k % dist];
-                    // all sources precede nU, all destinations follow it, so lanes never race.
-                    long long src = nU - dist;
-                    for (int k = lane; k < val; k += 64) {
-                        int kk = k < dist ? k : k % dist;
-                        uint8_t v = L.win[(src + kk) & (D4G_WIN - 1)];
-                        L.win[(nU + k) & (D4G_WIN - 1)] = v;
-                        if (nU + k < in.uCap) U[in.uBase + nU + k] = v;
-                    }
-                    nU += val;
-                }
-            }
-            if (status != 0) break;
-            if (lane == 0) {
-                S->litlenBits = litlenBits;
-                S->sizeBits = S->hdrBits + litlenBits;
-                S->valid = 1;
-                S->maskSlot = 0;
-            }
-            __syncthreads();
-            blkSize = S->sizeBits;
-            if (nStates < in.stCap) {
-                D4GState* g = pstates + in.stBase + nStates;
-                for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
-                stateIdx = (int)nStates;
-            }
-            nStates++;
-            __syncthreads();
         }
-        if (lane == 0 && nBlocks < in.blkCap) {
-            D4GParsedBlock pb;
-            pb.type = btype;
-            pb.stateIdx = stateIdx;
-            pb.tokStart = blkTok0;
-            pb.tokCount = nTok - blkTok0;
-            pb.uStart = blkU0;
-            pb.uLen = nU - blkU0;
-            pb.sizeBits = blkSize;
-            pblocks[in.blkBase + nBlocks] = pb;
-        }
-        // DeflateStream.getSizeBits; DeflateBlockUncompressed.getSizeBits alignment (:70-74)
-        streamBits += 3;
-        if (btype == 0) {
-            long long c = streamBits % 8;
-            c = c == 0 ? 0 : 8 - c;
-            streamBits += ((nU - blkU0) + 4) * 8 + c;
-        } else {
-            streamBits += blkSize;
-        }
-        nBlocks++;
+        long long np = (bytePos + len) * 8;
+        if (np > br.nbits) { np = br.nbits; po.eofHit = 1; }
+        po.endBit = np;
+        po.uLen = len;
+        po.status = 0;
+        return;
     }
-    bool overflow = nTok > in.tokCap || nU > in.uCap || nBlocks > in.blkCap || nStates > in.stCap;
-    long long pos = __shfl((long long)br.pos, 0);
+    for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)S)[i] = 0;
+    __syncthreads();
+    if (btype == 1) {
+        // The fixed code (HuffmanTable.LIT, B/huffman/HuffmanTable.java:166-209) is the RFC 1951 code over
+        // 288 symbols; 286/287 take code space but are not decodable symbols (decodeStream rejects > 285).
+        for (int i = lane; i < D4G_NLIT; i += 64) S->litLen[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+        for (int i = lane; i < D4G_NDIST; i += 64) S->distLen[i] = i < 30 ? 5 : 0;
+        if (lane == 0) S->type = D4G_FIXED;
+        __syncthreads();
+    } else {
+        // initDynamicDecoder — DeflateBlockHuffman.java:892-1010
+        long long r = 0;
+        if (lane == 0) {
+            if (!br.have(14)) r = -1;
+            else {
+                br.fill(L.inbuf);
+                S->nLit = (int)(br.buf & 31) + 257;
+                S->nDist = (int)((br.buf >> 5) & 31) + 1;
+                S->nCl = (int)((br.buf >> 10) & 15) + 4;
+                br.skip(14);
+                if (S->nLit > 288) r = -1;
+                if (strict && (S->nLit > 286 || S->nDist > 30)) r = -1;
+                if (r == 0 && !br.have(3 * S->nCl)) r = -1;
+                if (r == 0) {
+                    for (int i = 0; i < S->nCl; i++) {
+                        br.fill(L.inbuf);
+                        S->clLen[D4G_CL_ORDER[i]] = (uint8_t)(br.buf & 7);
+                        br.skip(3);
+                    }
+                }
+                S->type = D4G_DYNAMIC;
+                S->hdrBits = 5 + 5 + 4 + 3 * S->nCl;
+            }
+        }
+        r = __shfl(r, 0);
+        if (r < 0) return;
+        d4g_build_decoder(&L.cl, S->clLen, 19);
+        if (lane == 0) {
+            int i = 0, np = 0;
+            int combined = S->nLit + S->nDist;
+            while (i < combined && r == 0) {
+                br.fill(L.inbuf);
+                int cl = 0, sym;
+                D4G_DECODE(&L.cl, br.buf, br.nbits - br.pos, sym, cl);
+                if (sym < 0 || sym > 18) { r = -1; break; }
+                br.skip(cl);
+                S->hdrBits += cl;
+                int run = 0, value = sym;
+                if (sym == 16) {
+                    if (i < 1 || !br.have(2)) { r = -1; break; }
+                    run = (int)(br.buf & 3) + 3;
+                    br.skip(2); S->hdrBits += 2;
+                    value = (i - 1 < S->nLit) ? S->litLen[i - 1] : S->distLen[i - 1 - S->nLit];
+                } else if (sym == 17) {
+                    if (!br.have(3)) { r = -1; break; }
+                    run = (int)(br.buf & 7) + 3;
+                    br.skip(3); S->hdrBits += 3;
+                    value = 0;
+                } else if (sym == 18) {
+                    if (!br.have(7)) { r = -1; break; }
+                    run = (int)(br.buf & 127) + 11;
+                    br.skip(7); S->hdrBits += 7;
+                    value = 0;
+                }
+                int cnt = run ? run : 1;
+                if (i + cnt > combined) { r = -1; break; }
+                for (int k = 0; k < cnt; k++, i++) {
+                    if (i < S->nLit) S->litLen[i] = (uint8_t)value;
+                    else S->distLen[i - S->nLit] = (uint8_t)value;
+                }
+                S->pairs[np++] = pair_encode(sym, run, value);
+            }
+            S->nPairs = np;
+        }
+        r = __shfl(r, 0);
+        if (r < 0) return;
+    }
+    d4g_build_decoder(&L.lit, S->litLen, btype == 1 ? 288 : S->nLit);
+    d4g_build_decoder(&L.dist, S->distLen, btype == 1 ? 30 : S->nDist);
+    if (btype == 1 && lane == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
+    if (strict) {
+        // speculative candidates must look like an encoder's output: complete literal/length code with an
+        // EOB code, complete (or at most one-code) distance code
+        bool good = L.lit.complete && S->litLen[256] > 0 && (L.dist.complete || L.dist.nCodes <= 1);
+        if (!good) return;
+    }
+    // ---- decodeStream — DeflateBlockHuffman.java:778-890: lane 0 decodes, the wave refills the input chunk ----
+    long long litlenBits = 0, nTok = 0, nU = 0, needHist = 0;
+    int done = 0;  // 1 EOB, -1 failure
+    while (true) {
+        long long code = 0;
+        if (lane == 0) {
+            while (true) {
+                if (br.near_end() && br.inBase + D4G_INCH < sd.len + 16) { code = 2; break; }  // refill needed
+                br.fill(L.inbuf);
+                uint64_t bits = br.buf;
+                long long avail = br.nbits - br.pos;
+                int cl = 0, val = 0, dist = 0, edge = 0, used = 0;
+                int sym;
+                D4G_DECODE(&L.lit, bits, avail, sym, cl);
+                if (sym < 0 || sym > 285) { code = -1; break; }
+                if (sym <= 256) { val = sym; used = cl; if (EMIT) S->hist[sym]++; }
+                else {
+                    int eb = d4g_lsym_ebits(sym);
+                    int len = d4g_lsym_base(sym);
+                    used = cl + eb;
+                    if (used > avail) { code = -1; break; }
+                    len += (int)((bits >> cl) & ((1u << eb) - 1));
+                    edge = (len == 258 && sym == 284);
+                    int dcl = 0, ds;
+                    D4G_DECODE(&L.dist, bits >> used, avail - used, ds, dcl);
+                    if (ds < 0 || ds > 29) { code = -1; break; }
+                    int deb = d4g_dsym_ebits(ds);
+                    if (used + dcl + deb > avail) { code = -1; break; }
+                    dist = d4g_dsym_base(ds) + (int)((bits >> (used + dcl)) & ((1u << deb) - 1));
+                    used += dcl + deb;
+                    if (dist - nU > needHist) needHist = dist - nU;
+                    if (EMIT) { S->hist[sym]++; S->hist[D4G_NLIT + ds]++; }
+                    val = len;
+                }
+                br.skip(used);
+                litlenBits += used;
+                if (EMIT) {
+                    out.tokA[em->tokStart + nTok] = (uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16);
+                    out.tokOff[em->tokStart + nTok] = (uint32_t)(em->uStart + nU);
+                }
+                nTok++;
+                if (sym == 256) { code = 1; break; }
+                nU += dist ? val : 1;
+            }
+        }
+        code = __shfl(code, 0);
+        if (code == 2) {
+            long long bitpos = __shfl((long long)br.pos, 0);
+            stage(bitpos);
+            continue;
+        }
+        done = (int)code;
+        break;
+    }
+    if (done < 0) return;
     if (lane == 0) {
-        D4GStreamOut o;
-        o.status = status < 0 ? -1 : (overflow ? 1 : 0);
-        o.nBlocks = nBlocks;
-        o.nTok = nTok;
-        o.nU = nU;
-        o.nStates = nStates;
-        if (pos > br.nbits) pos = br.nbits;
-        o.consumedBytes = (pos + 7) >> 3;
-        o.sizeBits = streamBits;
-        outs[blockIdx.x] = o;
+        S->litlenBits = litlenBits;
+        S->sizeBits = S->hdrBits + litlenBits;
+        S->valid = 1;
+        S->maskSlot = 0;
+    }
+    __syncthreads();
+    po.status = 0;
+    po.endBit = __shfl((long long)br.pos, 0);
+    po.nTok = __shfl(nTok, 0);
+    po.uLen = __shfl(nU, 0);
+    po.sizeBits = S->sizeBits;
+    po.needHist = __shfl(needHist, 0);
+    if (EMIT) {
+        D4GState* g = out.states + em->stateIdx;
+        for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n) {
+    if (blockIdx.x >= n) return;
+    const D4GProbeIn pi = in[blockIdx.x];
+    D4GProbeOut po;
+    D4GParseOut none = {nullptr, nullptr, nullptr, nullptr};
+    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
+    if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
+}
+
+__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
+    const D4GEmitIn em = in[blockIdx.x];
+    D4GProbeOut po;
+    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out);
+    if ((threadIdx.x & 63) == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. Decoded bytes by pointer jumping.  src[q] (u32, stream-relative) is the position byte q
+// copies from; literals and stored bytes point at themselves.
+// ---------------------------------------------------------------------------------------
+struct D4GTokRange { int32_t stream; int32_t stored; long long tokStart, tokCount, uStart, uLen; };
+
+__global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, const D4GTokRange* ranges, const uint32_t* tokA,
+                                                  const uint32_t* tokOff, uint8_t* U, uint32_t* src, int32_t* badDist, int G) {
+    const D4GTokRange r = ranges[blockIdx.x / G];
+    const D4GStreamDesc sd = streams[r.stream];
+    uint32_t* s = src + sd.uBase;
+    uint8_t* u = U + sd.uBase;
+    long long stride = (long long)G * blockDim.x;
+    long long t0 = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x;
+    if (r.stored) {
+        for (long long k = t0; k < r.uLen; k += stride) s[r.uStart + k] = (uint32_t)(r.uStart + k);
+        return;
+    }
+    for (long long t = t0; t < r.tokCount; t += stride) {
+        uint32_t a = tokA[r.tokStart + t];
+        uint32_t pos = tokOff[r.tokStart + t];
+        int dist = tok_dist(a), val = tok_val(a);
+        if (dist == 0) {
+            if (val < 256) { u[pos] = (uint8_t)val; s[pos] = pos; }
+        } else if ((uint32_t)dist > pos) {
+            badDist[r.stream] = 1;  // reference: readSlice walks off the first block (NullPointerException)
+            for (int k = 0; k < val; k++) s[pos + k] = pos + k;
+        } else {
+            for (int k = 0; k < val; k++) s[pos + k] = pos + k - dist;
+        }
+    }
+}
+
+// One stream per blockIdx.y.  In place: reading a concurrently updated entry still yields an ancestor.
+__global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* streams, uint32_t* src, int32_t* changed, int G) {
+    const D4GStreamDesc sd = streams[blockIdx.x / G];
+    uint32_t* s = src + sd.uBase;
+    long long stride = (long long)G * blockDim.x;
+    int any = 0;
+    for (long long q = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q < sd.uLen; q += stride) {
+        uint32_t a = s[q];
+        if (a != (uint32_t)q) {
+            uint32_t b = s[a];
+            if (b != a) { s[q] = b; any = 1; }
+        }
+    }
+    unsigned long long m = __ballot(any);
+    if (m && (threadIdx.x & 63) == 0) atomicOr((unsigned*)changed, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_resolve_streams(const D4GStreamDesc* streams, const uint32_t* src, uint8_t* U, int G) {
+    const D4GStreamDesc sd = streams[blockIdx.x / G];
+    const uint32_t* s = src + sd.uBase;
+    uint8_t* u = U + sd.uBase;
+    long long stride = (long long)G * blockDim.x;
+    for (long long q = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q < sd.uLen; q += stride) {
+        uint32_t a = s[q];
+        if (a != (uint32_t)q) u[q] = u[a];
     }
 }

@@ -168,8 +168,8 @@ int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
         std::lock_guard<std::mutex> lk(g_mu);
         try {
             engine().init();
-            b->impl.parse();
-            const D4GStreamOut& o = b->impl.pouts[0];
+            b->impl.parse_probe();
+            const Batch::PStream& o = b->impl.ps[0];
             *bits = o.status == 0 ? o.sizeBits : (int64_t)len * 8;  // B/Deft.java:48-54
             rc = D4G_OK;
         } catch (const std::exception& ex) {
@@ -193,9 +193,10 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
         std::lock_guard<std::mutex> lk(g_mu);
         try {
             engine().init();
-            b->impl.parse();
-            const D4GStreamOut& o = b->impl.pouts[0];
-            if (consumed) *consumed = (size_t)o.consumedBytes;
+            b->impl.parse_probe();
+            b->impl.build_blocks(false, false);
+            const Batch::PStream& o = b->impl.ps[0];
+            if (consumed) *consumed = (size_t)o.consumed;
             if (o.status != 0) {
                 *status = D4G_STREAM_PARSE_ERROR;
             } else {

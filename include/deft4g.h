@@ -39,6 +39,8 @@ typedef struct d4g_stats {
     int64_t rounds, kernel_launches;
     int64_t search_bytes_algorithmic; /* C_in + U + C_out summed over streams */
     double ms_search_kernels;         /* device time of the candidate-search kernels (HIP events on the library's stream) */
+    double ms_parse_kernels;          /* device time of scan + probe + emit + pointer-jumping kernels */
+    int64_t scan_candidates, scan_confirmed, exact_probes, jump_rounds;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.
