@@ -93,17 +93,27 @@ def main():
 
     ms_step = elapsed * 1000.0 / args.steps
     value = (n * world / 1e6) / (elapsed / args.steps)  # whole-job MB/s of uncompressed input
-    # dominant kernel by device time (HIP events on the library's stream)
-    kern = {"k_parse": st["ms_parse"], "candidate_search": st["ms_search_kernels"]}
-    dom = max(kern, key=kern.get)
-    if dom == "k_parse":
-        alg = st["bytes_in"] + st["bytes_decoded"] + 8 * st["n_tokens"]  # tokenise: C_in + U + 8N
-        launches = 1
-    else:
-        alg = st["search_bytes_algorithmic"]  # C_in + U + C_out per stream
-        launches = 1
-    dur_s = kern[dom] / 1000.0 / launches
+    # Dominant kernel = k_exec_state_ops (profiles/: ~67 % of device time).  One launch runs one dependency level
+    # of the search program over every active block: algorithmically one pass over the tokens plus the decoded
+    # bytes the literal-cost evaluation touches, 8N + min(U, 48*refs) (SURVEY.md §8d "cost-eval"; refs <= N).
+    n_tok, n_u = st["n_tokens"], st["bytes_decoded"]
+    alg = 8 * n_tok + min(n_u, 48 * n_tok)
+    launches = max(1, st["state_launches"])
+    dur_s = st["ms_state_kernels"] / 1000.0 / launches  # HIP events around each launch on the library's stream
     achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
+    dom = "k_exec_state_ops"
+    kern = {dom: st["ms_state_kernels"]}
+    # HBM traffic per launch of that kernel: FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this
+    # same command (separate passes; FETCH_SIZE left uncorrected — the accesses are not the wide coalesced
+    # stream the guide's x2 applies to), newest profiles/*_pmc_fetch_write_summary.json
+    traffic = None
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_summary.json")))[-1]
+        pm = json.load(open(f))
+        traffic = int((pm["FETCH_SIZE"][dom]["per_dispatch_MB"] + pm["WRITE_SIZE"][dom]["per_dispatch_MB"]) * 1e6)
+    except Exception:  # noqa: BLE001
+        traffic = None
     line = {
         "metric": "input MB/s on raw-deflate optimise (mode NONE)",
         "value": round(value, 3), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -115,21 +125,23 @@ def main():
                    "saved_bits": res["saved_bits"], "roundtrip_ok": bool(ok)},
         "phases_ms": {k: round(st[k], 2) for k in ("ms_parse", "ms_optimise", "ms_merge", "ms_write", "ms_total")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                     "algorithmic_bytes": int(alg), "kernel_ms": round(kern[dom], 3)},
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": int(alg), "launches_per_step": launches,
+                     "avg_launch_ms": round(dur_s * 1000.0, 4), "kernel_ms_per_step": round(kern[dom], 3),
+                     "parse_kernels_ms": round(st["ms_parse_kernels"], 3), "search_kernels_ms": round(st["ms_search_kernels"], 3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (single-thread C++ restatement; the reference's mode NONE is single-threaded,
         # K/DeflateFilesContainer.java:22) on a bounded sample of the same workload.
         import oracle_lib as O
-        sample_n = 1 << 20
+        sample_n = 16 << 20
         sraw = synth.reptext(sample_n, 0xD4F7)
         sstream = synth.deflate9(sraw)
         t0 = time.perf_counter()
         O.optimise(sstream, bool(args.merge))
         cs = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": round(sample_n / 1e6 / cs, 4), "unit": "MB/s", "cores": 1, "kind": "port",
-                                "sample": "first 1 MiB of the same generator (seed 0xD4F7), zlib-9 stream, %.1f s of CPU" % cs}
+                                "sample": "first 16 MiB of the same generator (seed 0xD4F7), zlib-9 stream, %.1f s of CPU" % cs}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -27,7 +27,8 @@ class d4g_stats(ctypes.Structure):
                [(n, ctypes.c_int64) for n in ("n_streams", "n_blocks", "n_tokens", "bytes_in", "bytes_decoded", "bytes_out",
                                               "rounds", "kernel_launches", "search_bytes_algorithmic")] + \
                [("ms_search_kernels", ctypes.c_double), ("ms_parse_kernels", ctypes.c_double)] + \
-               [(n, ctypes.c_int64) for n in ("scan_candidates", "scan_confirmed", "exact_probes", "jump_rounds")]
+               [(n, ctypes.c_int64) for n in ("scan_candidates", "scan_confirmed", "exact_probes", "jump_rounds")] + \
+               [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64)]
 
 
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",

@@ -578,13 +578,19 @@ struct Batch {
             rt_h2d(dActive, sub.data(), sub.size() * sizeof(int32_t));
             D4GCtx c = make_ctx(P, nA);
             RtEvent e0, e1;
+            std::vector<std::unique_ptr<RtEvent>> evs;
             e0.record();
             i64 groups = (nA + 7) / 8;
             for (int l = 0; l < P.nLevels; l++) {
                 if (P.stateOff[l].second) {
                     i64 grid = 8 * groups * P.stateOff[l].second;
+                    evs.emplace_back(new RtEvent());
+                    evs.back()->record();
                     RT_LAUNCH(k_exec_state_ops, grid, state_block(), c, P.dLists + P.stateOff[l].first, P.stateOff[l].second);
+                    evs.emplace_back(new RtEvent());
+                    evs.back()->record();
                     stats.kernel_launches++;
+                    stats.state_launches++;
                 }
                 if (P.hdrOff[l].second) {
                     i64 grid = 8 * groups * P.hdrOff[l].second;
@@ -598,6 +604,7 @@ struct Batch {
             std::vector<D4GRoundResult> r(sub.size());
             rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
             msSearch += rt_elapsed_ms(e0, e1);
+            for (size_t k = 0; k + 1 < evs.size(); k += 2) stats.ms_state_kernels += rt_elapsed_ms(*evs[k], *evs[k + 1]);
             for (size_t k = 0; k < sub.size(); k++) {
                 res[subPos[k]] = r[k];
                 gpuType[sub[k]] = r[k].newType;

@@ -184,7 +184,7 @@ struct D4GScanTile { int32_t stream; int32_t pad; long long byteStart; };
 
 __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* streams, const D4GScanTile* tiles, D4GProbeIn* cands,
                                                       unsigned* nCands, unsigned capCands) {
-    __shared__ alignas(16) uint8_t buf[D4G_SCAN_TILE + 32];
+    alignas(16) __shared__ uint8_t buf[D4G_SCAN_TILE + 32];
     const D4GScanTile tile = tiles[blockIdx.x];
     const D4GStreamDesc sd = streams[tile.stream];
     for (int i = threadIdx.x * 16; i < D4G_SCAN_TILE + 32; i += blockDim.x * 16)

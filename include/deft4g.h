@@ -41,6 +41,8 @@ typedef struct d4g_stats {
     double ms_search_kernels;         /* device time of the candidate-search kernels (HIP events on the library's stream) */
     double ms_parse_kernels;          /* device time of scan + probe + emit + pointer-jumping kernels */
     int64_t scan_candidates, scan_confirmed, exact_probes, jump_rounds;
+    double ms_state_kernels;          /* summed device time of k_exec_state_ops launches (HIP events around each launch) */
+    int64_t state_launches;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

@@ -123,7 +123,7 @@ inline void rt_d2h(void* h, const void* d, size_t n) { if (n) memcpy(h, d, n); }
 inline void rt_d2d(void* d, const void* s, size_t n) { if (n) memmove(d, s, n); }
 inline void rt_memset(void* d, int v, size_t n) { if (n) memset(d, v, n); }
 inline void rt_sync() {}
-struct RtEvent { void record() {} };
+struct RtEvent { void record() {} };  // timing is meaningless in the emulator
 inline float rt_elapsed_ms(RtEvent&, RtEvent&) { return 0.f; }
 #define RT_CHECK(x) (x)
 #define RT_LAUNCH(kern, grid, block, ...) (hipsim::sim().kname = #kern, hipsim::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kern(__VA_ARGS__); }))
