@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "d4g_ops.h"
@@ -48,32 +50,115 @@ struct Program {
     D4GOp* dOps = nullptr;
     int32_t* dLists = nullptr;
     std::vector<std::pair<size_t, int>> stateOff, hdrOff;
+    int nRequested = 0;  // ops the plain unrolling would have emitted (for the record)
 
-    int new_slot(int level) { slotLevel.push_back(level); return nSlots++; }
-    int emit(int kind, int src, bool hasDst, int arg, bool cand, bool needMask) {
+    // ---- symbolic identity of a state, used to emit every distinct computation once ----
+    // A state is determined by (m, c, h): token mask, code lengths, header — each the result of a
+    // symbolic function application of the ops below — plus g, the guard under which the reference
+    // builds it at all (a null optimiseBlockNormal result or an unchanged recodedHuffmanFull removes
+    // whole subtrees).  Two requests with the same key are the same computation on the same data, so
+    // the later one can only repeat an earlier candidate of equal size and never wins the strict `<`.
+    struct Sym { int m, c, h, g; };
+    std::vector<Sym> sym;               // per slot
+    std::map<std::vector<int>, int> ids;      // symbolic function application -> id
+    std::map<std::vector<int>, int> slotOf;   // op key -> slot
+    std::set<std::vector<int>> offered, searched;
+    int nextId = 1;
+    int id_of(std::vector<int> key) {
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        return ids[key] = nextId++;
+    }
+
+    int new_slot(int level, Sym sy) { slotLevel.push_back(level); sym.push_back(sy); return nSlots++; }
+    int emit_raw(int kind, int src, int dst, int arg, bool cand, bool needMask, int level) {
         D4GOp op;
         memset(&op, 0, sizeof(op));
-        int level = slotLevel[src] + 1;
         op.kind = kind;
         op.src = src;
-        op.dst = hasDst ? new_slot(level) : -1;
+        op.dst = dst;
         op.arg = arg;
         op.seq = cand ? (int)ops.size() : -1;
         op.maskSlot = needMask ? nMasks++ : -1;
         op.scratch = -1;
         op.scratchMask = -1;
         if (kind == OP_RECODE_FULL) {
-            op.scratch = new_slot(level); new_slot(level);
+            op.scratch = new_slot(level, sym[src]); new_slot(level, sym[src]);
             op.scratchMask = nMasks; nMasks += 2;
         }
         ops.push_back(op);
         opLevel.push_back(level);
-        return op.dst;
+        return (int)ops.size() - 1;
     }
-    int OPT(int src, bool requireSaved, bool cand) { return emit(OP_OPT, src, true, requireSaved ? 1 : 0, cand, true); }
-    int RECODE(int src, bool prune, bool cand) { return emit(OP_RECODE, src, true, prune ? 1 : 0, cand, prune); }
-    int FULL(int src, bool cand) { return emit(OP_RECODE_FULL, src, true, 0, cand, true); }
-    int LEAST(int src, int mode) { return emit(OP_LEAST, src, true, mode, false, true); }
+    // offer `slot` as a candidate at this point of the enumeration unless an equal state was offered before
+    void offer(int slot, int cond, int opIdx) {
+        const Sym& y = sym[slot];
+        std::vector<int> uncond = {y.m, y.c, y.h, y.g, 0}, withc = {y.m, y.c, y.h, y.g, cond};
+        bool dup = offered.count(uncond) || offered.count(withc);
+        if (dup) { if (opIdx >= 0) ops[opIdx].seq = -1; return; }
+        offered.insert(withc);
+        if (opIdx < 0) emit_raw(OP_CAND, slot, -1, 0, true, false, slotLevel[slot] + 1);
+    }
+    // generic state op: kind/arg applied to src; `cand` offers the result
+    int state_op(int kind, int src, int arg, bool cand, bool needMask) {
+        nRequested++;
+        const Sym x = sym[src];
+        Sym y = x;
+        int cond = 0;
+        switch (kind) {
+        case OP_RECODE:
+            if (arg & 1) y.m = id_of({OP_RECODE, x.m, x.c});
+            y.c = id_of({-1, y.m});          // code rebuilt from the histogram of mask y.m
+            y.h = id_of({-2, y.c});          // rewriteHeader(default flags) of those lengths
+            break;
+        case OP_OPT:
+            y.m = id_of({OP_OPT, x.m, x.c});
+            y.h = id_of({OP_OPT, x.h});
+            if (arg & 1) { cond = id_of({-3, x.m, x.c, x.h}); y.g = id_of({-4, x.g, cond}); }
+            break;
+        case OP_LEAST:
+            y.m = id_of({OP_LEAST, arg, x.m, x.c});
+            break;
+        case OP_POST: y.h = id_of({OP_POST, x.h}); break;
+        case OP_PRUNEHDR: y.h = id_of({OP_PRUNEHDR, x.h}); break;
+        case OP_RECODE_FULL:
+            y.m = id_of({OP_RECODE_FULL, 0, x.m, x.c, x.h});
+            y.c = id_of({OP_RECODE_FULL, 1, x.m, x.c, x.h});
+            y.h = id_of({OP_RECODE_FULL, 2, x.m, x.c, x.h});
+            cond = id_of({-5, x.m, x.c, x.h});
+            y.g = id_of({-4, x.g, cond});
+            break;
+        case OP_TOFIXED_OPT:
+            y.m = id_of({OP_TOFIXED_OPT, x.m});
+            y.c = id_of({-6});
+            y.h = 0;
+            break;
+        default: break;
+        }
+        std::vector<int> key = {kind, arg, x.m, x.c, x.h, x.g};
+        auto it = slotOf.find(key);
+        if (it != slotOf.end()) {
+            if (cand) offer(it->second, cond, -1);
+            return it->second;
+        }
+        int level = slotLevel[src] + 1;
+        int dst = new_slot(level, y);
+        int opIdx = emit_raw(kind, src, dst, arg, cand, needMask, level);
+        slotOf[key] = dst;
+        if (cand) offer(dst, cond, opIdx);
+        return dst;
+    }
+    int OPT(int src, bool requireSaved, bool cand) { return state_op(OP_OPT, src, requireSaved ? 1 : 0, cand, true); }
+    int RECODE(int src, bool prune, bool cand) { return state_op(OP_RECODE, src, prune ? 1 : 0, cand, prune); }
+    int FULL(int src, bool cand) { return state_op(OP_RECODE_FULL, src, 0, cand, true); }
+    int LEAST(int src, int mode) { return state_op(OP_LEAST, src, mode, false, true); }
+    void HS(int base) {  // the 56 header candidates depend only on the base's token bits and code lengths
+        nRequested++;
+        const Sym& y = sym[base];
+        std::vector<int> key = {y.m, y.c, y.g};
+        if (!searched.insert(key).second) return;
+        emit_raw(OP_HDRSEARCH, base, -1, 0, true, false, slotLevel[base] + 1);
+    }
 
     void aor(int t) {  // addOptimisedRecoded — DeflateStream.java:265-317
         int b1 = OPT(t, false, false);
@@ -81,23 +166,24 @@ struct Program {
         int pruned = RECODE(t, true, false);
         int b3 = OPT(pruned, false, false);
         int b4 = OPT(FULL(pruned, false), false, false);
-        emit(OP_HDRSEARCH, b1, false, 0, true, false);
-        emit(OP_HDRSEARCH, b2, false, 0, true, false);
-        emit(OP_HDRSEARCH, b3, false, 0, true, false);
-        emit(OP_HDRSEARCH, b4, false, 0, true, false);
+        HS(b1);
+        HS(b2);
+        HS(b3);
+        HS(b4);
     }
     void run(int x) {  // runOptimisationsCallback — :400-442
-        int post = emit(OP_POST, x, true, 0, true, false);
+        int post = state_op(OP_POST, x, 0, true, false);
         OPT(post, true, true);
         aor(post);
-        int prune = emit(OP_PRUNEHDR, x, true, 0, true, false);
+        int prune = state_op(OP_PRUNEHDR, x, 0, true, false);
         OPT(prune, true, true);
         aor(prune);
         aor(LEAST(x, 0));
         aor(LEAST(x, 1));
     }
     void multi(int e) {  // runOptimisationsCallbackMulti — :443-463
-        emit(OP_CAND, e, false, 0, true, false);
+        nRequested++;
+        offer(e, 0, -1);
         run(e);
         int hr = RECODE(e, false, true);
         run(hr);
@@ -108,7 +194,10 @@ struct Program {
     }
     void build(bool fixedOrigin) {
         slotLevel.assign(1, 0);
+        sym.assign(1, Sym{id_of({-10}), id_of({-11}), id_of({-12}), 0});
         int T = 0;
+        // the current block itself is the incumbent: candidates equal to it can never be strictly smaller
+        offered.insert({sym[0].m, sym[0].c, sym[0].h, 0, 0});
         int optimised = OPT(T, true, true);  // op 0: "optimised"; the stored candidate (host) ranks right after it
         int H, OH;
         if (fixedOrigin) {
@@ -120,9 +209,36 @@ struct Program {
         }
         multi(H);
         multi(OH);
-        if (!fixedOrigin) emit(OP_TOFIXED_OPT, H, true, 0, true, true);  // "default fixed-huffman"
+        if (!fixedOrigin) state_op(OP_TOFIXED_OPT, H, 0, true, true);  // "default fixed-huffman"
         multi(LEAST(H, 0));
         multi(LEAST(H, 1));
+        // drop ops whose result feeds no candidate and no header search (e.g. bases of a repeated search)
+        {
+            std::vector<int> producer(nSlots, -1);
+            for (size_t i = 0; i < ops.size(); i++)
+                if (ops[i].dst >= 0) producer[ops[i].dst] = (int)i;
+            std::vector<char> live(ops.size(), 0);
+            std::vector<int> stack;
+            for (size_t i = 0; i < ops.size(); i++)
+                if (ops[i].seq >= 0 || ops[i].kind == OP_HDRSEARCH || ops[i].kind == OP_CAND) { live[i] = 1; stack.push_back((int)i); }
+            while (!stack.empty()) {
+                int i = stack.back();
+                stack.pop_back();
+                int pr = producer[ops[i].src];
+                if (pr >= 0 && !live[pr]) { live[pr] = 1; stack.push_back(pr); }
+            }
+            std::vector<D4GOp> kept;
+            std::vector<int> keptLevel;
+            for (size_t i = 0; i < ops.size(); i++)
+                if (live[i]) {
+                    D4GOp o = ops[i];
+                    if (o.seq >= 0) o.seq = (int)kept.size();
+                    kept.push_back(o);
+                    keptLevel.push_back(opLevel[i]);
+                }
+            ops.swap(kept);
+            opLevel.swap(keptLevel);
+        }
         nLevels = 0;
         for (int l : opLevel) nLevels = std::max(nLevels, l + 1);
         stateLevels.assign(nLevels, {});

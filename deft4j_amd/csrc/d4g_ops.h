@@ -61,6 +61,33 @@ D4G_DEV int backref_cost(const D4GState* S, int len, int edge, int dist, int& ls
     return S->litLen[lsym] + d4g_lsym_ebits(lsym) + S->distLen[dsym] + d4g_dsym_ebits(dsym);
 }
 
+// Walk the decoded bytes [p, p+len) with aligned 32-bit loads (the next word is requested before the
+// current one is consumed); fn(byte) returns false to stop early.  U is padded, so the aligned
+// word holding the last byte is always readable.
+template <typename Fn>
+D4G_DEV void for_bytes(const uint8_t* p, int len, Fn fn) {
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
+    int skip = (int)(a & 3);
+    uint32_t cur = *w++ >> (8 * skip);
+    int have = 4 - skip, k = 0;
+    while (true) {
+        int n = have < len - k ? have : len - k;
+        bool more = k + n < len;
+        uint32_t nxt = 0;
+        if (more) nxt = *w++;
+        for (int j = 0; j < n; j++) {
+            if (!fn((int)(cur & 0xff))) return;
+            cur >>= 8;
+        }
+        k += n;
+        if (!more) return;
+        cur = nxt;
+        have = 4;
+    }
+}
+#define D4G_LONG_TOKEN 32  // back-references longer than this are summed by the whole wave
+
 // ---------------------------------------------------------------------------------------
 // replaceBackrefsWithLiteralsIfSmaller — DeflateBlockHuffman.java:312-319 over :222-296.
 // One lane per token, 64 tokens per wave step; the new mask word is the wave ballot.
@@ -85,18 +112,19 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
                 const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
                 int total = 0;
                 bool ok = true;
-                for (int k = 0; k < len; k++) {
-                    int bs = S->litLen[p[k]];
-                    if (bs < 1) { ok = false; break; }
+                for_bytes(p, len, [&](int b) {
+                    int bs = S->litLen[b];
+                    if (bs < 1) { ok = false; return false; }
                     total += bs;
-                    if (prune ? total > cost : total >= cost) { ok = false; break; }
-                }
+                    if (prune ? total > cost : total >= cost) { ok = false; return false; }
+                    return true;
+                });
                 if (ok) {
                     bit = 1;
                     saved += cost - total;
                     atomicSub(&S->hist[lsym], 1u);
                     atomicSub(&S->hist[D4G_NLIT + dsym], 1u);
-                    for (int k = 0; k < len; k++) atomicAdd(&S->hist[p[k]], 1u);
+                    for_bytes(p, len, [&](int b) { atomicAdd(&S->hist[b], 1u); return true; });
                 }
             }
         }
@@ -125,25 +153,53 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
         for (long long w = wave; w < b.maskWords; w += nw) {
             long long t = w * 64 + lane;
             uint64_t mw = maskIn[w];
+            int len = 0, cost = 0, bin = 0;
+            long long off = 0;
+            bool act = false;
             if (t < b.tokCount && !((mw >> lane) & 1)) {
                 uint32_t a = c.tokA[b.tokStart + t];
                 int dist = tok_dist(a);
                 if (dist > 0) {
-                    int len = tok_val(a), lsym, dsym;
-                    int cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
-                    int bin = lsym - 257;
+                    int lsym, dsym;
+                    len = tok_val(a);
+                    cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
+                    bin = lsym - 257;
+                    off = c.tokOff[b.tokStart + t];
+                    act = true;
                     atomicOr(&flags[1], 1u << bin);
-                    const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
-                    int total = 0;
-                    bool ok = true;
-                    for (int k = 0; k < len; k++) {
-                        int bs = S->litLen[p[k]];
-                        if (bs < 1) { ok = false; break; }
-                        total += bs;
-                    }
-                    if (!ok) atomicOr(&flags[0], 1u << bin);
-                    else { atomicAdd(&binSize[bin], total - cost); atomicAdd(&binFreq[bin], 1); }
                 }
+            }
+            int total = 0;
+            bool ok = true;
+            if (act && len <= D4G_LONG_TOKEN) {
+                for_bytes(c.U + b.uBase + off, len, [&](int by) {
+                    int bs = S->litLen[by];
+                    if (bs < 1) { ok = false; return false; }
+                    total += bs;
+                    return true;
+                });
+            }
+            // long back-references: the whole wave sums one token at a time (coalesced byte loads)
+            unsigned long long ml = __ballot(act && len > D4G_LONG_TOKEN);
+            while (ml) {
+                int srcLane = __ffsll((long long)ml) - 1;
+                ml &= ml - 1;
+                long long o2 = __shfl(off, srcLane);
+                int l2 = __shfl(len, srcLane);
+                const uint8_t* p2 = c.U + b.uBase + o2;
+                int tsum = 0, bad = 0;
+                for (int k = lane; k < l2; k += 64) {
+                    int bs = S->litLen[p2[k]];
+                    bad |= bs < 1;
+                    tsum += bs;
+                }
+                tsum = (int)wave_sum_i64(tsum);
+                unsigned long long mb = __ballot(bad);
+                if (lane == srcLane) { total = tsum; ok = mb == 0; }
+            }
+            if (act) {
+                if (!ok) atomicOr(&flags[0], 1u << bin);
+                else { atomicAdd(&binSize[bin], total - cost); atomicAdd(&binFreq[bin], 1); }
             }
         }
     }
@@ -165,20 +221,34 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
         long long t = w * 64 + lane;
         uint64_t mw = maskIn[w];
         int bit = (int)((mw >> lane) & 1);
+        int len = 0;
+        long long off = 0;
+        bool hit = false;
         if (rem >= 0 && t < b.tokCount && !bit) {
             uint32_t a = c.tokA[b.tokStart + t];
             int dist = tok_dist(a);
             if (dist > 0) {
-                int len = tok_val(a);
+                len = tok_val(a);
                 int lsym = d4g_len2sym(len, tok_edge(a));
                 if (lsym - 257 == rem) {
                     bit = 1;
-                    const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
+                    hit = true;
+                    off = c.tokOff[b.tokStart + t];
                     atomicSub(&S->hist[lsym], 1u);
                     atomicSub(&S->hist[D4G_NLIT + d4g_dist2sym(dist)], 1u);
-                    for (int k = 0; k < len; k++) atomicAdd(&S->hist[p[k]], 1u);
                 }
             }
+        }
+        if (hit && len <= D4G_LONG_TOKEN)
+            for_bytes(c.U + b.uBase + off, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
+        unsigned long long ml = __ballot(hit && len > D4G_LONG_TOKEN);
+        while (ml) {
+            int srcLane = __ffsll((long long)ml) - 1;
+            ml &= ml - 1;
+            long long o2 = __shfl(off, srcLane);
+            int l2 = __shfl(len, srcLane);
+            const uint8_t* p2 = c.U + b.uBase + o2;
+            for (int k = lane; k < l2; k += 64) atomicAdd(&S->hist[p2[k]], 1u);
         }
         uint64_t nm = __ballot(bit);
         if (lane == 0) maskOut[w] = nm;

@@ -84,18 +84,28 @@ struct D4GBitReader {
         buf = 0;
         cnt = 0;
         nextByte = bitpos >> 3;
-        fill(inbuf);
-        int sh = (int)(bitpos & 7);
-        buf >>= sh;
-        cnt -= sh;
-    }
-    __device__ void fill(const uint8_t* inbuf) {
-        while (cnt <= 56) {
+        // byte loads up to the next 4-byte boundary of the staged chunk, then aligned words
+        while ((nextByte - inBase) & 3) {
             long long o = nextByte - inBase;
             uint64_t v = (o >= 0 && o < D4G_INCH + 16) ? inbuf[o] : 0;
             buf |= v << cnt;
             cnt += 8;
             nextByte++;
+        }
+        fill(inbuf);
+        int sh = (int)(bitpos & 7);
+        buf >>= sh;
+        cnt -= sh;
+        fill(inbuf);
+    }
+    // Guarantees at least 33 valid bits (enough for one code + its extra bits).
+    __device__ void fill(const uint8_t* inbuf) {
+        while (cnt <= 32) {
+            long long o = nextByte - inBase;
+            uint64_t v = (o >= 0 && o + 4 <= D4G_INCH + 16) ? *(const uint32_t*)(inbuf + o) : 0;
+            buf |= v << cnt;
+            cnt += 32;
+            nextByte += 4;
         }
     }
     __device__ bool have(int n) const { return pos + n <= nbits; }
@@ -405,7 +415,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                 int sym;
                 D4G_DECODE(&L.lit, bits, avail, sym, cl);
                 if (sym < 0 || sym > 285) { code = -1; break; }
-                if (sym <= 256) { val = sym; used = cl; if (EMIT) S->hist[sym]++; }
+                if (sym <= 256) { val = sym; used = cl; if (EMIT) S->hist[sym]++; br.skip(used); }
                 else {
                     int eb = d4g_lsym_ebits(sym);
                     int len = d4g_lsym_base(sym);
@@ -413,18 +423,22 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                     if (used > avail) { code = -1; break; }
                     len += (int)((bits >> cl) & ((1u << eb) - 1));
                     edge = (len == 258 && sym == 284);
+                    br.skip(used);
+                    br.fill(L.inbuf);           // second refill: distance code + extra bits (<= 28 bits)
+                    bits = br.buf;
+                    avail = br.nbits - br.pos;
                     int dcl = 0, ds;
-                    D4G_DECODE(&L.dist, bits >> used, avail - used, ds, dcl);
+                    D4G_DECODE(&L.dist, bits, avail, ds, dcl);
                     if (ds < 0 || ds > 29) { code = -1; break; }
                     int deb = d4g_dsym_ebits(ds);
-                    if (used + dcl + deb > avail) { code = -1; break; }
-                    dist = d4g_dsym_base(ds) + (int)((bits >> (used + dcl)) & ((1u << deb) - 1));
+                    if (dcl + deb > avail) { code = -1; break; }
+                    dist = d4g_dsym_base(ds) + (int)((bits >> dcl) & ((1u << deb) - 1));
+                    br.skip(dcl + deb);
                     used += dcl + deb;
                     if (dist - nU > needHist) needHist = dist - nU;
                     if (EMIT) { S->hist[sym]++; S->hist[D4G_NLIT + ds]++; }
                     val = len;
                 }
-                br.skip(used);
                 litlenBits += used;
                 if (EMIT) {
                     out.tokA[em->tokStart + nTok] = (uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16);

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs
             } else if ((mask[t >> 6] >> (t & 63)) & 1) {
                 kind = 3;
                 const uint8_t* p = Ub + c.tokOff[b.tokStart + t];
-                for (int k = 0; k < val; k++) nbits += S->litLen[p[k]];
+                for_bytes(p, val, [&](int by) { nbits += S->litLen[by]; return true; });
             } else {
                 kind = 2;
                 int ls, ds;
@@ -176,11 +176,12 @@ __global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs
         } else if (kind == 3) {
             int len = tok_val(a);
             const uint8_t* p = Ub + c.tokOff[b.tokStart + t];
-            for (int k = 0; k < len; k++) {
-                int l = S->litLen[p[k]];
-                put_bits(out, pos, W.litCode[p[k]], l);
+            for_bytes(p, len, [&](int by) {
+                int l = S->litLen[by];
+                put_bits(out, pos, W.litCode[by], l);
                 pos += l;
-            }
+                return true;
+            });
         }
         __syncthreads();
         if (threadIdx.x == 0) W.base += total;

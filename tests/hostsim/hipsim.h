@@ -97,6 +97,7 @@ inline T __shfl_up(T v, int delta) {
 }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 
 template <typename T>
 inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
