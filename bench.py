@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--mib", type=int, default=64, help="uncompressed MiB per stream (64 = BASELINE config 2)")
     ap.add_argument("--merge", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="override the HIP device index (rehearsal: several ranks on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -41,12 +43,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dev = local if args.device is None else args.device
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import deft4j_amd as D
     import synth
-    D.init(local)
+    D.init(local if args.device is None else args.device)
+    tdev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
 
     # --- workload: one independent stream per rank (per-file sharding) ---
     n = args.mib << 20
@@ -71,7 +78,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -85,7 +92,7 @@ def main():
     sizes = [len(stream), len(out), res["saved_bits"]]
     if dist is not None:
         # the path's only exchange: gather (in_len, out_len, saved_bits) of every shard on rank 0 (RCCL over xGMI)
-        mine = torch.tensor(sizes, device="cuda", dtype=torch.int64)
+        mine = torch.tensor(sizes, device=tdev, dtype=torch.int64)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
     for b in batches:

@@ -294,6 +294,7 @@ struct Engine {  // per-process device objects shared by all batches
     Program progDyn, progFixed;
     uint8_t* dHdrTables = nullptr;  // flags[64] + prune[64]
     int32_t* dErrors = nullptr;
+    long long* dOpStats = nullptr;
     int slotsPerBlock = 0, masksPerBlock = 0, maxOps = 0;
     bool ready = false;
     void init() {
@@ -309,6 +310,8 @@ struct Engine {  // per-process device objects shared by all batches
         rt_h2d(dHdrTables, tab, 128);
         dErrors = (int32_t*)rt_malloc(4);
         rt_memset(dErrors, 0, 4);
+        dOpStats = (long long*)rt_malloc(64 * 8);
+        rt_memset(dOpStats, 0, 64 * 8);
         rt_sync();
         slotsPerBlock = std::max(progDyn.nSlots, progFixed.nSlots);
         masksPerBlock = std::max(progDyn.nMasks, progFixed.nMasks);
@@ -382,7 +385,7 @@ struct Batch {
         D4GCtx c;
         c.tokA = dTokA; c.tokOff = dTokOff; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
-        c.active = dActive; c.errors = E.dErrors; c.nActive = nActive; c.nOps = (int)P.ops.size();
+        c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
         return c;
     }
@@ -697,7 +700,20 @@ struct Batch {
             std::vector<std::unique_ptr<RtEvent>> evs;
             e0.record();
             i64 groups = (nA + 7) / 8;
+            // Level l's header searches read bases produced at level l-1, so they run on the second stream
+            // beside level l's state ops (the searches are LDS-bound at low occupancy, the state ops are
+            // issue-bound: together they fill the CUs better than back to back).
+            std::vector<std::unique_ptr<RtEvent>> lvlDone;
+            RtEvent startEv;
+            startEv.record();
+            rt_stream2_wait(startEv);  // stream 2 must see the uploaded active list / previous round
             for (int l = 0; l < P.nLevels; l++) {
+                if (P.hdrOff[l].second) {
+                    if (!lvlDone.empty()) rt_stream2_wait(*lvlDone.back());
+                    i64 grid = 8 * groups * P.hdrOff[l].second;
+                    RT_LAUNCH2(k_exec_hdr_search, grid, 64, c, P.dLists + P.hdrOff[l].first, P.hdrOff[l].second);
+                    stats.kernel_launches++;
+                }
                 if (P.stateOff[l].second) {
                     i64 grid = 8 * groups * P.stateOff[l].second;
                     evs.emplace_back(new RtEvent());
@@ -708,12 +724,12 @@ struct Batch {
                     stats.kernel_launches++;
                     stats.state_launches++;
                 }
-                if (P.hdrOff[l].second) {
-                    i64 grid = 8 * groups * P.hdrOff[l].second;
-                    RT_LAUNCH(k_exec_hdr_search, grid, 64, c, P.dLists + P.hdrOff[l].first, P.hdrOff[l].second);
-                    stats.kernel_launches++;
-                }
+                lvlDone.emplace_back(new RtEvent());
+                lvlDone.back()->record();
             }
+            RtEvent hsDone;
+            hsDone.record2();
+            rt_stream_wait(hsDone);
             RT_LAUNCH(k_select, nA, state_block(), c, dResults);
             stats.kernel_launches++;
             e1.record();

@@ -16,6 +16,7 @@ struct D4GCtx {
     const uint8_t* hdrPrune;  // [56] its `prune` loop variable
     const int32_t* active;    // [nActive] block indices to run
     int32_t* errors;          // device error counter
+    long long* opStats;       // optional per-op-kind cycle accounting (D4G_PROFILE_OPS builds), else null
     int32_t nActive;
     int32_t nOps;
     int32_t slotsPerBlock;
@@ -465,6 +466,9 @@ __device__ void wg_recode_to_fixed(D4GLds* L) {
 // ---------------------------------------------------------------------------------------
 __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId) {
     const D4GOp op = c.ops[opId];
+#ifdef D4G_PROFILE_OPS
+    long long tStart = clock64();
+#endif
     const D4GBlock b = c.blocks[blk];
     D4GState* S = &L->st;
     const D4GState* src = state_ptr(c, blk, op.src);
@@ -560,6 +564,12 @@ __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId)
         *keyp = (op.seq >= 0 && S->valid) ? D4G_MAKE_KEY(S->sizeBits, (long long)opId * 64) : D4G_KEY_NONE;
     }
     wg_store_state(dst, S);
+#ifdef D4G_PROFILE_OPS
+    if (threadIdx.x == 0 && c.opStats) {
+        atomicAdd((unsigned long long*)&c.opStats[op.kind * 2 + (op.arg & 1) * 32], (unsigned long long)(clock64() - tStart));
+        atomicAdd((unsigned long long*)&c.opStats[op.kind * 2 + 1 + (op.arg & 1) * 32], 1ULL);
+    }
+#endif
 }
 
 // XCD-aware (block, op) mapping: workgroups g and g+8 share an XCD (and its L2), so all ops

@@ -19,6 +19,7 @@
 
 struct RtGlobals {
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // header searches run beside the next level's state ops
     int device = -1;
     bool ready = false;
 };
@@ -51,7 +52,15 @@ struct RtEvent {
     RtEvent() { RT_CHECK(hipEventCreate(&e)); }
     ~RtEvent() { if (e) (void)hipEventDestroy(e); }
     void record() { RT_CHECK(hipEventRecord(e, rt().stream)); }
+    void record2() { RT_CHECK(hipEventRecord(e, rt().stream2)); }
 };
+inline void rt_stream2_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().stream2, ev.e, 0)); }
+inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().stream, ev.e, 0)); }
+#define RT_LAUNCH2(kern, grid, block, ...)                                                          \
+    do {                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().stream2, __VA_ARGS__); \
+        RT_CHECK(hipGetLastError());                                                                \
+    } while (0)
 inline float rt_elapsed_ms(RtEvent& a, RtEvent& b) {
     RT_CHECK(hipEventSynchronize(b.e));
     float ms = 0;

@@ -35,6 +35,7 @@ int d4g_init(int device_index) {
         if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
         RT_CHECK(hipSetDevice(device_index));
         if (!rt().stream) RT_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
+        if (!rt().stream2) RT_CHECK(hipStreamCreateWithFlags(&rt().stream2, hipStreamNonBlocking));
         rt().device = device_index;
 #endif
         rt().ready = true;
@@ -215,5 +216,14 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
 }
 
 void d4g_free(void* p) { free(p); }
+
+#ifdef D4G_PROFILE_OPS
+// profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
+int d4g_debug_opstats(long long* out64) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    rt_d2h(out64, engine().dOpStats, 64 * 8);
+    return 0;
+}
+#endif
 
 }  // extern "C"

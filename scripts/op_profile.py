@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Dev tool: build libdeft4g with -DD4G_PROFILE_OPS and print mean cycles per search-program op kind."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+so = os.path.join(ROOT, "gpurun_out", "libdeft4g_prof.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-DD4G_PROFILE_OPS", "-shared", "-fPIC",
+                       "-o", so, os.path.join(ROOT, "deft4j_amd", "csrc", "libdeft4g.hip")])
+import deft4j_amd as D, synth
+L = D.load_library(so); D.init(0, lib=L)
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+s = synth.make_stream(mib << 20)
+for it in range(2):
+    b = D.Batch([s], lib=L).run(False); st = b.stats(); b.close()
+buf = (ctypes.c_longlong * 64)()
+L.d4g_debug_opstats(buf)
+names = {1: "OPT", 2: "RECODE", 3: "FULL", 4: "LEAST", 5: "POST", 6: "PRUNEHDR", 7: "TOFIXED"}
+print("ms_optimise %.1f state_ms %.1f" % (st["ms_optimise"], st["ms_state_kernels"]))
+for arg in (0, 1):
+    for k, nm in names.items():
+        cyc, n = buf[k * 2 + arg * 32], buf[k * 2 + 1 + arg * 32]
+        if n:
+            print("%-9s arg&1=%d  n=%8d  mean %9.0f cycles (%.1f us @2.4GHz)  total %.1f Gcyc" % (nm, arg, n, cyc / n, cyc / n / 2400.0, cyc / 1e9))

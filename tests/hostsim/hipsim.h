@@ -124,7 +124,10 @@ inline void rt_d2h(void* h, const void* d, size_t n) { if (n) memcpy(h, d, n); }
 inline void rt_d2d(void* d, const void* s, size_t n) { if (n) memmove(d, s, n); }
 inline void rt_memset(void* d, int v, size_t n) { if (n) memset(d, v, n); }
 inline void rt_sync() {}
-struct RtEvent { void record() {} };  // timing is meaningless in the emulator
+struct RtEvent { void record() {} void record2() {} };  // timing is meaningless in the emulator
+inline void rt_stream2_wait(RtEvent&) {}
+inline void rt_stream_wait(RtEvent&) {}
 inline float rt_elapsed_ms(RtEvent&, RtEvent&) { return 0.f; }
 #define RT_CHECK(x) (x)
+#define RT_LAUNCH2(kern, grid, block, ...) RT_LAUNCH(kern, grid, block, __VA_ARGS__)
 #define RT_LAUNCH(kern, grid, block, ...) (hipsim::sim().kname = #kern, hipsim::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kern(__VA_ARGS__); }))
