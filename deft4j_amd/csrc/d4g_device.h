@@ -116,26 +116,26 @@ D4G_DEV int wg_max_i32(int v, long long* red) {
 template <typename W, typename I, int MAXN>
 struct TreeMem {
     W* weight;   // [2*MAXN]
-    I* left;     // [2*MAXN]
-    I* right;    // [2*MAXN]
+    I* left;     // [MAXN]    children of internal node id live at index id - nl
+    I* right;    // [MAXN]
     I* parent;   // [2*MAXN]  (bit (8*sizeof(I)-1) = side)
-    I* heap;     // [MAXN]
-    I* value;    // [MAXN]   symbol of leaf
-    I* firstAt;  // [MAXN+1] first leaf (DFS order) at each depth
-    I* depth;    // [MAXN]   depth of each leaf
+    I* heap;     // [MAXN+1]  the priority queue; reused as firstAt once the tree is built
+    I* value;    // [MAXN]    symbol of leaf
+    I* firstAt;  // = heap    first leaf (DFS order) at each depth
+    I* depth;    // [MAXN]    depth of each leaf
     static constexpr int NONE = (1 << (8 * sizeof(I) - 1)) - 1;
     static constexpr int SIDE = 1 << (8 * sizeof(I) - 1);
     static constexpr size_t bytes(int lanes) {
-        return (size_t)lanes * (sizeof(W) * 2 * MAXN + sizeof(I) * (2 * MAXN * 3 + MAXN * 4 + 1));
+        return (size_t)lanes * (sizeof(W) * 2 * MAXN + sizeof(I) * (MAXN * 2 + 2 * MAXN + (MAXN + 1) + MAXN * 2));
     }
     __device__ void carve(unsigned char* base, int lanes) {
         weight = (W*)base; base += sizeof(W) * 2 * MAXN * lanes;
-        left = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
-        right = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
+        left = (I*)base; base += sizeof(I) * MAXN * lanes;
+        right = (I*)base; base += sizeof(I) * MAXN * lanes;
         parent = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
-        heap = (I*)base; base += sizeof(I) * MAXN * lanes;
+        heap = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
         value = (I*)base; base += sizeof(I) * MAXN * lanes;
-        firstAt = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
+        firstAt = heap;
         depth = (I*)base;
     }
 };
@@ -213,8 +213,8 @@ __device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int 
         int r = pq_remove();
         int id = nn++;
         TM(weight, id) = (W)(TM(weight, l) + TM(weight, r));
-        TM(left, id) = (I)l;
-        TM(right, id) = (I)r;
+        TM(left, id - nl) = (I)l;
+        TM(right, id - nl) = (I)r;
         TM(parent, l) = (I)id;
         TM(parent, r) = (I)(id | SIDE);
         pq_add(id);
@@ -227,13 +227,13 @@ __device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int 
         maxDepth = 0;
         int node = root, depth = 0;
         while (true) {
-            while (node >= nl) { node = TM(left, node); depth++; }
+            while (node >= nl) { node = TM(left, node - nl); depth++; }
             TM(depth, node) = (I)depth;
             if (TM(firstAt, depth) == (I)NONE) TM(firstAt, depth) = (I)node;
             if (depth > maxDepth) maxDepth = depth;
             while (node != root && (TM(parent, node) & SIDE)) { node = TM(parent, node) & ~SIDE; depth--; }
             if (node == root) break;
-            node = TM(right, TM(parent, node) & ~SIDE);
+            node = TM(right, (TM(parent, node) & ~SIDE) - nl);
         }
     };
     traverse();
@@ -242,11 +242,11 @@ __device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int 
         int leafA = TM(firstAt, maxDepth);
         int pa = TM(parent, leafA);
         int p1 = pa & ~SIDE;
-        int leafB = (pa & SIDE) ? TM(left, p1) : TM(right, p1);
+        int leafB = (pa & SIDE) ? TM(left, p1 - nl) : TM(right, p1 - nl);
         int pp = TM(parent, p1);
         int p2 = pp & ~SIDE;
-        if (pp & SIDE) { TM(right, p2) = (I)leafB; TM(parent, leafB) = (I)(p2 | SIDE); }
-        else { TM(left, p2) = (I)leafB; TM(parent, leafB) = (I)p2; }
+        if (pp & SIDE) { TM(right, p2 - nl) = (I)leafB; TM(parent, leafB) = (I)(p2 | SIDE); }
+        else { TM(left, p2 - nl) = (I)leafB; TM(parent, leafB) = (I)p2; }
         bool moved = false;
         for (int i = maxDepth - 2; i >= 1; i--) {
             int leafC = TM(firstAt, i);
@@ -254,12 +254,12 @@ __device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int 
                 int pc = TM(parent, leafC);
                 int p3 = pc & ~SIDE;
                 int in = p1;  // the detached parent's slot is reused for new InternalNode(leafA, leafC)
-                TM(left, in) = (I)leafA;
-                TM(right, in) = (I)leafC;
+                TM(left, in - nl) = (I)leafA;
+                TM(right, in - nl) = (I)leafC;
                 TM(parent, leafA) = (I)in;
                 TM(parent, leafC) = (I)(in | SIDE);
-                if (pc & SIDE) { TM(right, p3) = (I)in; TM(parent, in) = (I)(p3 | SIDE); }
-                else { TM(left, p3) = (I)in; TM(parent, in) = (I)p3; }
+                if (pc & SIDE) { TM(right, p3 - nl) = (I)in; TM(parent, in) = (I)(p3 | SIDE); }
+                else { TM(left, p3 - nl) = (I)in; TM(parent, in) = (I)p3; }
                 moved = true;
                 break;
             }

@@ -29,7 +29,13 @@ static inline int state_block() {
     const char* e = getenv("D4G_SIM_BLOCK");
     if (e) return atoi(e);
 #endif
-    return 256;
+    static int v = 0;
+    if (!v) {
+        const char* t = getenv("D4G_STATE_BLOCK");  // tuning knob: 64, 128 or 256
+        v = t ? atoi(t) : 128;
+        if (v != 64 && v != 128 && v != 256) v = 128;
+    }
+    return v;
 }
 
 static inline double now_ms() {
