@@ -103,9 +103,11 @@ def main():
     # Dominant kernel = k_exec_state_ops (profiles/: ~67 % of device time).  One launch runs one dependency level
     # of the search program over every active block: algorithmically one pass over the tokens plus the decoded
     # bytes the literal-cost evaluation touches, 8N + min(U, 48*refs) (SURVEY.md §8d "cost-eval"; refs <= N).
-    n_tok, n_u = st["n_tokens"], st["bytes_decoded"]
-    alg = 8 * n_tok + min(n_u, 48 * n_tok)
     launches = max(1, st["state_launches"])
+    # a launch covers one block group (stream lane) at one level: mean tokens / decoded bytes per launch
+    n_tok = st["state_tokens_per_round"] / launches
+    n_u = st["state_bytes_per_round"] / launches
+    alg = int(8 * n_tok + min(n_u, 48 * n_tok))
     dur_s = st["ms_state_kernels"] / 1000.0 / launches  # HIP events around each launch on the library's stream
     achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
     dom = "k_exec_state_ops"

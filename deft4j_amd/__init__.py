@@ -28,7 +28,8 @@ class d4g_stats(ctypes.Structure):
                                               "rounds", "kernel_launches", "search_bytes_algorithmic")] + \
                [("ms_search_kernels", ctypes.c_double), ("ms_parse_kernels", ctypes.c_double)] + \
                [(n, ctypes.c_int64) for n in ("scan_candidates", "scan_confirmed", "exact_probes", "jump_rounds")] + \
-               [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64)]
+               [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64), ("state_tokens_per_round", ctypes.c_int64),
+                ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64)]
 
 
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",

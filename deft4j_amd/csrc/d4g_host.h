@@ -38,6 +38,17 @@ static inline int state_block() {
     return v;
 }
 
+static inline int lanes() {
+    static int v = 0;
+    if (!v) {
+        const char* t = getenv("D4G_LANES");  // tuning knob: block groups running their level sequences concurrently
+        v = t ? atoi(t) : 2;  // measured on MI355X: 1 -> 587, 2 -> 627, 4 -> 494, 8 -> 349 MB/s on config 2
+        if (v < 1) v = 1;
+        if (v > RT_MAX_LANES) v = RT_MAX_LANES;
+    }
+    return v;
+}
+
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -700,49 +711,69 @@ struct Batch {
                 if (gpuType[act[i]] == wantType) { sub.push_back(act[i]); subPos.push_back(i); }
             if (sub.empty()) continue;
             int nA = (int)sub.size();
+            rt().cur = 0;
             rt_h2d(dActive, sub.data(), sub.size() * sizeof(int32_t));
-            D4GCtx c = make_ctx(P, nA);
-            RtEvent e0, e1;
-            std::vector<std::unique_ptr<RtEvent>> evs;
+            RtEvent e0, e1, uploaded;
+            uploaded.record();
+            std::vector<std::unique_ptr<RtEvent>> evs, keep;
             e0.record();
-            i64 groups = (nA + 7) / 8;
-            // Level l's header searches read bases produced at level l-1, so they run on the second stream
-            // beside level l's state ops (the searches are LDS-bound at low occupancy, the state ops are
-            // issue-bound: together they fill the CUs better than back to back).
-            std::vector<std::unique_ptr<RtEvent>> lvlDone;
-            RtEvent startEv;
-            startEv.record();
-            rt_stream2_wait(startEv);  // stream 2 must see the uploaded active list / previous round
-            for (int l = 0; l < P.nLevels; l++) {
-                if (P.hdrOff[l].second) {
-                    if (!lvlDone.empty()) rt_stream2_wait(*lvlDone.back());
-                    i64 grid = 8 * groups * P.hdrOff[l].second;
-                    RT_LAUNCH2(k_exec_hdr_search, grid, 64, c, P.dLists + P.hdrOff[l].first, P.hdrOff[l].second);
-                    stats.kernel_launches++;
+            // Split the active blocks into groups, one stream lane each: the launch tail of one group's level
+            // (a few long recode/tree ops) overlaps the other groups' levels.
+            int G = std::min(lanes(), std::max(1, nA / 16));
+            std::vector<std::unique_ptr<RtEvent>> laneDone;
+            for (int g = 0; g < G; g++) {
+                int lo = (int)((i64)nA * g / G), hi = (int)((i64)nA * (g + 1) / G);
+                if (hi <= lo) continue;
+                rt().cur = g;
+                i64 tokSum = 0, uSum = 0;
+                for (int k = lo; k < hi; k++) { tokSum += hBlocks[sub[k]].tokCount; uSum += hBlocks[sub[k]].uLen; }
+                D4GCtx c = make_ctx(P, hi - lo);
+                c.active = dActive + lo;
+                rt_stream_wait(uploaded);
+                i64 groups = (hi - lo + 7) / 8;
+                // Level l's header searches read bases produced at level l-1, so they run on the lane's second
+                // stream beside level l's state ops (the searches are LDS-bound at low occupancy).
+                RtEvent* lvlPrev = nullptr;
+                rt_stream2_wait(uploaded);
+                for (int l = 0; l < P.nLevels; l++) {
+                    if (P.hdrOff[l].second) {
+                        if (lvlPrev) rt_stream2_wait(*lvlPrev);
+                        i64 grid = 8 * groups * P.hdrOff[l].second;
+                        RT_LAUNCH2(k_exec_hdr_search, grid, 64, c, P.dLists + P.hdrOff[l].first, P.hdrOff[l].second);
+                        stats.kernel_launches++;
+                    }
+                    if (P.stateOff[l].second) {
+                        i64 grid = 8 * groups * P.stateOff[l].second;
+                        evs.emplace_back(new RtEvent());
+                        evs.back()->record();
+                        RT_LAUNCH(k_exec_state_ops, grid, state_block(), c, P.dLists + P.stateOff[l].first, P.stateOff[l].second);
+                        evs.emplace_back(new RtEvent());
+                        evs.back()->record();
+                        stats.kernel_launches++;
+                        stats.state_launches++;
+                        stats.state_tokens_per_round += tokSum;
+                        stats.state_bytes_per_round += uSum;
+                    }
+                    keep.emplace_back(new RtEvent());
+                    keep.back()->record();
+                    lvlPrev = keep.back().get();
                 }
-                if (P.stateOff[l].second) {
-                    i64 grid = 8 * groups * P.stateOff[l].second;
-                    evs.emplace_back(new RtEvent());
-                    evs.back()->record();
-                    RT_LAUNCH(k_exec_state_ops, grid, state_block(), c, P.dLists + P.stateOff[l].first, P.stateOff[l].second);
-                    evs.emplace_back(new RtEvent());
-                    evs.back()->record();
-                    stats.kernel_launches++;
-                    stats.state_launches++;
-                }
-                lvlDone.emplace_back(new RtEvent());
-                lvlDone.back()->record();
+                keep.emplace_back(new RtEvent());
+                keep.back()->record2();
+                rt_stream_wait(*keep.back());
+                RT_LAUNCH(k_select, hi - lo, state_block(), c, dResults + lo);
+                stats.kernel_launches++;
+                laneDone.emplace_back(new RtEvent());
+                laneDone.back()->record();
             }
-            RtEvent hsDone;
-            hsDone.record2();
-            rt_stream_wait(hsDone);
-            RT_LAUNCH(k_select, nA, state_block(), c, dResults);
-            stats.kernel_launches++;
+            rt().cur = 0;
+            for (auto& ev : laneDone) rt_stream_wait(*ev);
             e1.record();
             std::vector<D4GRoundResult> r(sub.size());
             rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
             msSearch += rt_elapsed_ms(e0, e1);
             for (size_t k = 0; k + 1 < evs.size(); k += 2) stats.ms_state_kernels += rt_elapsed_ms(*evs[k], *evs[k + 1]);
+            stats.search_lanes = G;
             for (size_t k = 0; k < sub.size(); k++) {
                 res[subPos[k]] = r[k];
                 gpuType[sub[k]] = r[k].newType;

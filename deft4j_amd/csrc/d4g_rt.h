@@ -17,11 +17,17 @@
             throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
+#define RT_MAX_LANES 8
 struct RtGlobals {
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // header searches run beside the next level's state ops
+    // "lane" k = a pair of HIP streams: state ops on a[k], header searches on b[k].  Groups of deflate
+    // blocks run their level sequences on different lanes so that one group's launch tails overlap
+    // another group's work.  Lane 0 is the default stream of every other phase.
+    hipStream_t a[RT_MAX_LANES] = {nullptr};
+    hipStream_t b[RT_MAX_LANES] = {nullptr};
+    int cur = 0;
     int device = -1;
     bool ready = false;
+    hipStream_t& stream_ref() { return a[cur]; }
 };
 inline RtGlobals& rt() {
     static RtGlobals g;
@@ -33,17 +39,17 @@ inline void* rt_malloc(size_t n) {
     return p;
 }
 inline void rt_free(void* p) { if (p) (void)hipFree(p); }
-inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().stream)); }
+inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().a[rt().cur])); }
 inline void rt_d2h(void* h, const void* d, size_t n) {
-    if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().stream));
-    RT_CHECK(hipStreamSynchronize(rt().stream));
+    if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().a[rt().cur]));
+    RT_CHECK(hipStreamSynchronize(rt().a[rt().cur]));
 }
-inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().stream)); }
-inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().stream)); }
-inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().stream)); }
+inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().a[rt().cur])); }
+inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().a[rt().cur])); }
+inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().a[rt().cur])); }
 #define RT_LAUNCH(kern, grid, block, ...)                                                           \
     do {                                                                                            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().stream, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().a[rt().cur], __VA_ARGS__); \
         RT_CHECK(hipGetLastError());                                                                \
     } while (0)
 
@@ -51,14 +57,14 @@ struct RtEvent {
     hipEvent_t e = nullptr;
     RtEvent() { RT_CHECK(hipEventCreate(&e)); }
     ~RtEvent() { if (e) (void)hipEventDestroy(e); }
-    void record() { RT_CHECK(hipEventRecord(e, rt().stream)); }
-    void record2() { RT_CHECK(hipEventRecord(e, rt().stream2)); }
+    void record() { RT_CHECK(hipEventRecord(e, rt().a[rt().cur])); }
+    void record2() { RT_CHECK(hipEventRecord(e, rt().b[rt().cur])); }
 };
-inline void rt_stream2_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().stream2, ev.e, 0)); }
-inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().stream, ev.e, 0)); }
+inline void rt_stream2_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().b[rt().cur], ev.e, 0)); }
+inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().a[rt().cur], ev.e, 0)); }
 #define RT_LAUNCH2(kern, grid, block, ...)                                                          \
     do {                                                                                            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().stream2, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().b[rt().cur], __VA_ARGS__); \
         RT_CHECK(hipGetLastError());                                                                \
     } while (0)
 inline float rt_elapsed_ms(RtEvent& a, RtEvent& b) {

@@ -34,8 +34,10 @@ int d4g_init(int device_index) {
         if (e != hipSuccess || n <= 0) return fail(D4G_ERR_NODEVICE, "no HIP device available (libdeft4g has no CPU fallback)");
         if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
         RT_CHECK(hipSetDevice(device_index));
-        if (!rt().stream) RT_CHECK(hipStreamCreateWithFlags(&rt().stream, hipStreamNonBlocking));
-        if (!rt().stream2) RT_CHECK(hipStreamCreateWithFlags(&rt().stream2, hipStreamNonBlocking));
+        for (int k = 0; k < RT_MAX_LANES; k++) {
+            if (!rt().a[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().a[k], hipStreamNonBlocking));
+            if (!rt().b[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().b[k], hipStreamNonBlocking));
+        }
         rt().device = device_index;
 #endif
         rt().ready = true;

@@ -43,6 +43,8 @@ typedef struct d4g_stats {
     int64_t scan_candidates, scan_confirmed, exact_probes, jump_rounds;
     double ms_state_kernels;          /* summed device time of k_exec_state_ops launches (HIP events around each launch) */
     int64_t state_launches;
+    int64_t state_tokens_per_round, state_bytes_per_round; /* summed over k_exec_state_ops launches: tokens / decoded bytes of the blocks each launch covers */
+    int64_t search_lanes;             /* block groups whose level sequences run concurrently (stream lanes) */
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

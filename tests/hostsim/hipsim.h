@@ -108,8 +108,10 @@ inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 
 // ---- runtime half (mirrors d4g_rt.h) ----
+#define RT_MAX_LANES 8
 struct RtGlobals {
     void* stream = nullptr;
+    int cur = 0;
     int device = 0;
     bool ready = false;
 };
