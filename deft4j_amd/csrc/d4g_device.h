@@ -113,113 +113,113 @@ D4G_DEV int wg_max_i32(int v, long long* red) {
 //   W = weight type, I = node-index type, MAXN = max leaves.
 //   element i of an array lives at arr[i * stride + lane].
 // ---------------------------------------------------------------------------------------
-template <typename W, typename I, int MAXN>
+// Heap entries carry their weight (weight << IDBITS | node id), so one LDS read per heap slot decides a
+// sift step; node weights are never looked up separately.  H = heap entry type (u64 for the
+// literal/length and distance trees, u32 for the 19-symbol code-length tree).
+template <typename H, typename I, int MAXN>
 struct TreeMem {
-    W* weight;   // [2*MAXN]
+    H* heap;     // [MAXN+1]  the priority queue
     I* left;     // [MAXN]    children of internal node id live at index id - nl
     I* right;    // [MAXN]
     I* parent;   // [2*MAXN]  (bit (8*sizeof(I)-1) = side)
-    I* heap;     // [MAXN+1]  the priority queue; reused as firstAt once the tree is built
     I* value;    // [MAXN]    symbol of leaf
-    I* firstAt;  // = heap    first leaf (DFS order) at each depth
+    I* firstAt;  // [MAXN+1]  first leaf (DFS order) at each depth
     I* depth;    // [MAXN]    depth of each leaf
     static constexpr int NONE = (1 << (8 * sizeof(I) - 1)) - 1;
     static constexpr int SIDE = 1 << (8 * sizeof(I) - 1);
+    static constexpr int IDBITS = 8 * sizeof(I);
     static constexpr size_t bytes(int lanes) {
-        return (size_t)lanes * (sizeof(W) * 2 * MAXN + sizeof(I) * (MAXN * 2 + 2 * MAXN + (MAXN + 1) + MAXN * 2));
+        return (size_t)lanes * (sizeof(H) * (MAXN + 1) + sizeof(I) * (MAXN * 2 + 2 * MAXN + MAXN + (MAXN + 1) + MAXN));
     }
     __device__ void carve(unsigned char* base, int lanes) {
-        weight = (W*)base; base += sizeof(W) * 2 * MAXN * lanes;
+        heap = (H*)base; base += sizeof(H) * (MAXN + 1) * lanes;
         left = (I*)base; base += sizeof(I) * MAXN * lanes;
         right = (I*)base; base += sizeof(I) * MAXN * lanes;
         parent = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
-        heap = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
         value = (I*)base; base += sizeof(I) * MAXN * lanes;
-        firstAt = heap;
+        firstAt = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
         depth = (I*)base;
     }
 };
 
 // Returns 0 on success, 1 if the limiter could not rebalance (the reference throws there).
 // freq(i) reads symbol i's frequency; outLen(i, len) receives each symbol's code length.
-template <typename W, typename I, int MAXN, typename FreqFn, typename OutFn>
-__device__ int d4g_build_tree(TreeMem<W, I, MAXN>& m, int stride, int lane, int numSymbols, int limit, FreqFn freq,
+template <typename H, typename I, int MAXN, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree(TreeMem<H, I, MAXN>& m, int stride, int lane, int numSymbols, int limit, FreqFn freq,
                               OutFn outLen) {
-    const int NONE = TreeMem<W, I, MAXN>::NONE;
-    const int SIDE = TreeMem<W, I, MAXN>::SIDE;
+    const int NONE = TreeMem<H, I, MAXN>::NONE;
+    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
+    const int IDB = TreeMem<H, I, MAXN>::IDBITS;
+    const H IDMASK = ((H)1 << IDB) - 1;
 #define TM(arr, i) m.arr[(i) * stride + lane]
     int nl = 0, hs = 0;
-    // java.util.PriorityQueue.offer: append, sift up while key < parent (stop on >=)
-    auto pq_add = [&](int x) {
+    // java.util.PriorityQueue.offer: append, sift up while key < parent (stop on >=); keys compare by weight only
+    auto pq_add = [&](H x) {
         int k = hs++;
-        W wx = TM(weight, x);
+        H wx = x >> IDB;
         while (k > 0) {
             int p = (k - 1) >> 1;
-            int e = TM(heap, p);
-            if (wx >= TM(weight, e)) break;
-            TM(heap, k) = (I)e;
+            H e = TM(heap, p);
+            if (wx >= (e >> IDB)) break;
+            TM(heap, k) = e;
             k = p;
         }
-        TM(heap, k) = (I)x;
+        TM(heap, k) = x;
     };
     // PriorityQueue.poll: root out, last element sifts down; left child unless left > right; stop when key <= child
-    auto pq_remove = [&]() -> int {
-        int result = TM(heap, 0);
+    auto pq_remove = [&]() -> H {
+        H result = TM(heap, 0);
         int s = --hs;
-        int x = TM(heap, s);
+        H x = TM(heap, s);
         if (s != 0) {
-            W wx = TM(weight, x);
+            H wx = x >> IDB;
             int k = 0, half = s >> 1;
             while (k < half) {
                 int child = 2 * k + 1;
-                int c = TM(heap, child);
-                W wc = TM(weight, c);
+                H c = TM(heap, child);
                 int r = child + 1;
                 if (r < s) {
-                    int cr = TM(heap, r);
-                    W wr = TM(weight, cr);
-                    if (wc > wr) { c = cr; wc = wr; child = r; }
+                    H cr = TM(heap, r);
+                    if ((c >> IDB) > (cr >> IDB)) { c = cr; child = r; }
                 }
-                if (wx <= wc) break;
-                TM(heap, k) = (I)c;
+                if (wx <= (c >> IDB)) break;
+                TM(heap, k) = c;
                 k = child;
             }
-            TM(heap, k) = (I)x;
+            TM(heap, k) = x;
         }
         return result;
     };
     for (int i = 0; i < numSymbols; i++) {
         unsigned f = freq(i);
         if (f > 0) {
-            TM(weight, nl) = (W)f;
             TM(value, nl) = (I)i;
-            pq_add(nl);
+            pq_add(((H)f << IDB) | (H)nl);
             nl++;
         }
     }
     int index = 0;
     while (hs < 2) {  // dummy leaves — HuffmanTree.java:50-58
         if (index >= numSymbols || freq(index) == 0) {
-            TM(weight, nl) = (W)1;
             TM(value, nl) = (I)index;
-            pq_add(nl);
+            pq_add(((H)1 << IDB) | (H)nl);
             nl++;
         }
         index++;
     }
     int nn = nl;
     for (int i = 0; i < nl - 1; i++) {
-        int l = pq_remove();
-        int r = pq_remove();
+        H hl = pq_remove();
+        H hr = pq_remove();
+        int l = (int)(hl & IDMASK), r = (int)(hr & IDMASK);
         int id = nn++;
-        TM(weight, id) = (W)(TM(weight, l) + TM(weight, r));
         TM(left, id - nl) = (I)l;
         TM(right, id - nl) = (I)r;
         TM(parent, l) = (I)id;
         TM(parent, r) = (I)(id | SIDE);
-        pq_add(id);
+        pq_add((((hl >> IDB) + (hr >> IDB)) << IDB) | (H)id);
     }
-    int root = pq_remove();
+    int root = (int)(pq_remove() & IDMASK);
     int maxDepth = 0;
     // traverse — DFS, left before right; records each leaf's depth and the first leaf per depth
     auto traverse = [&]() {

@@ -49,6 +49,30 @@ static inline int lanes() {
     return v;
 }
 
+// Executor choice per round.  "persistent": dependency-driven work-queue kernels (no launch per level, no
+// tails) — wins while the round is latency-bound (few active blocks: nerd.png 115 -> 68 ms).  "levels": one
+// launch per program level over all active blocks — wins once there are enough blocks to fill the chip
+// (config 2, 332 blocks: 79 vs 87 ms).  D4G_EXEC=persistent|levels forces one; default switches at
+// D4G_PERSIST_MAX_BLOCKS active blocks.
+static inline int exec_persistent(int nActive = 0) {
+    static int mode = -1, maxBlocks = 128;
+    if (mode < 0) {
+        const char* t = getenv("D4G_EXEC");
+        mode = !t ? 2 : !strcmp(t, "levels") ? 0 : !strcmp(t, "persistent") ? 1 : 2;
+        const char* m = getenv("D4G_PERSIST_MAX_BLOCKS");
+        if (m) maxBlocks = atoi(m);
+    }
+#ifdef D4G_HOSTSIM
+    return mode == 0 ? 0 : 1;
+#endif
+    if (mode == 2) return nActive <= maxBlocks ? 1 : 0;
+    return mode;
+}
+static inline int env_int(const char* name, int def) {
+    const char* t = getenv(name);
+    return t ? atoi(t) : def;
+}
+
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -66,6 +90,8 @@ struct Program {
     std::vector<std::vector<int>> stateLevels, hdrLevels;
     D4GOp* dOps = nullptr;
     int32_t* dLists = nullptr;
+    int32_t *dStateFlat = nullptr, *dHdrFlat = nullptr;  // level-ordered op ids for the persistent executor
+    int nStateFlat = 0, nHdrFlat = 0;
     std::vector<std::pair<size_t, int>> stateOff, hdrOff;
     int nRequested = 0;  // ops the plain unrolling would have emitted (for the record)
 
@@ -275,6 +301,17 @@ struct Program {
         }
         dLists = (int32_t*)rt_malloc(lists.size() * sizeof(int32_t));
         rt_h2d(dLists, lists.data(), lists.size() * sizeof(int32_t));
+        std::vector<int32_t> sf, hf;
+        for (int l = 0; l < nLevels; l++) {
+            sf.insert(sf.end(), stateLevels[l].begin(), stateLevels[l].end());
+            hf.insert(hf.end(), hdrLevels[l].begin(), hdrLevels[l].end());
+        }
+        nStateFlat = (int)sf.size();
+        nHdrFlat = (int)hf.size();
+        dStateFlat = (int32_t*)rt_malloc(sf.size() * sizeof(int32_t) + 16);
+        dHdrFlat = (int32_t*)rt_malloc(hf.size() * sizeof(int32_t) + 16);
+        rt_h2d(dStateFlat, sf.data(), sf.size() * sizeof(int32_t));
+        rt_h2d(dHdrFlat, hf.data(), hf.size() * sizeof(int32_t));
         rt_sync();
     }
 };
@@ -378,7 +415,7 @@ struct Batch {
     d4g_stats stats;
     // device
     uint8_t* dIn = nullptr;
-    uint32_t *dTokA = nullptr, *dTokOff = nullptr;
+    uint2* dTok = nullptr;
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -387,20 +424,23 @@ struct Batch {
     int32_t* dActive = nullptr;
     D4GRoundResult* dResults = nullptr;
     uint32_t* dOut = nullptr;
+    int32_t* dReady = nullptr;   // per (block, slot): epoch of the round that produced it (persistent executor)
+    unsigned* dHeads = nullptr;
+    int epoch = 0;
     std::vector<D4GBlock> hBlocks;  // device block descriptors (host copy)
     std::vector<int> gpuType;       // current state type per device block
     i64 outWords = 0;
     bool ran = false;
 
     ~Batch() {
-        rt_free(dIn); rt_free(dTokA); rt_free(dTokOff); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
-        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc);
+        rt_free(dIn); rt_free(dTok); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tokA = dTokA; c.tokOff = dTokOff; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -634,8 +674,7 @@ struct Batch {
         }
         size_t nb = hBlocks.size();
         rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
-        dTokA = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
-        dTokOff = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
+        dTok = (uint2*)rt_malloc((size_t)tokTot * 8 + 64);
         dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
         dSrc = (uint32_t*)rt_malloc((size_t)uTot * 4 + 64);
         if (nb) {
@@ -643,7 +682,12 @@ struct Batch {
             rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
             dStates = (D4GState*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(D4GState));
             dMasks = (uint64_t*)rt_malloc((size_t)maskWordsTotal * 8 + 64);
-            if (needSlots) dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
+            if (needSlots) {
+                dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
+                dReady = (int32_t*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(int32_t));
+                rt_memset(dReady, 0, nb * (size_t)slotsAlloc * sizeof(int32_t));
+                dHeads = (unsigned*)rt_malloc(64);
+            }
             dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
             dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
             // mask 0 of every block starts empty (no back-reference expanded)
@@ -656,7 +700,7 @@ struct Batch {
             // 3. emit
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
-            D4GParseOut po = {dTokA, dTokOff, dU, dStates};
+            D4GParseOut po = {dTok, dU, dStates};
             RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors);
             stats.kernel_launches++;
             // 4. decoded bytes
@@ -665,7 +709,7 @@ struct Batch {
             int32_t* dBad = (int32_t*)rt_malloc(n * 4 + 16);
             rt_memset(dBad, 0, n * 4 + 16);
             const int GF = 8;
-            RT_LAUNCH(k_fill_src, ranges.size() * GF, 256, dStreams, dRanges, dTokA, dTokOff, dU, dSrc, dBad, GF);
+            RT_LAUNCH(k_fill_src, ranges.size() * GF, 256, dStreams, dRanges, dTok, dU, dSrc, dBad, GF);
             stats.kernel_launches++;
             i64 maxU = 0;
             for (size_t i = 0; i < n; i++) maxU = std::max(maxU, ps[i].nU);
@@ -712,11 +756,58 @@ struct Batch {
             if (sub.empty()) continue;
             int nA = (int)sub.size();
             rt().cur = 0;
+            int xoff[9] = {0};
+            const bool persist = exec_persistent(nA) != 0;
+            if (persist) {
+                // group the active blocks by (position mod 8): one task queue per XCD
+                std::vector<int32_t> g;
+                std::vector<size_t> gp;
+                for (int x = 0; x < 8; x++) {
+                    xoff[x] = (int)g.size();
+                    for (size_t i = x; i < sub.size(); i += 8) { g.push_back(sub[i]); gp.push_back(subPos[i]); }
+                }
+                xoff[8] = (int)g.size();
+                sub.swap(g);
+                subPos.swap(gp);
+            }
             rt_h2d(dActive, sub.data(), sub.size() * sizeof(int32_t));
             RtEvent e0, e1, uploaded;
             uploaded.record();
             std::vector<std::unique_ptr<RtEvent>> evs, keep;
             e0.record();
+            if (persist) {
+                D4GCtx c = make_ctx(P, nA);
+                epoch++;
+                rt_memset(dHeads, 0, 64);
+                D4GQueue qs = {P.dStateFlat, P.nStateFlat, dHeads, dReady, epoch, {0}};
+                D4GQueue qh = {P.dHdrFlat, P.nHdrFlat, dHeads + 8, dReady, epoch, {0}};
+                for (int x = 0; x < 9; x++) { qs.xoff[x] = xoff[x]; qh.xoff[x] = xoff[x]; }
+                RtEvent ready;
+                ready.record();
+                rt_stream2_wait(ready);
+                static const int cus = device_cus();
+                static const int sPerCu = env_int("D4G_STATE_WGS_PER_CU", 8), hPerCu = env_int("D4G_HS_WGS_PER_CU", 4);
+                i64 ns = (i64)P.nStateFlat * nA, nh = (i64)P.nHdrFlat * nA;
+                i64 gs = std::min<i64>(ns, (i64)cus * sPerCu), gh = std::min<i64>(nh, (i64)cus * hPerCu);
+                evs.emplace_back(new RtEvent());
+                evs.back()->record();
+                RT_LAUNCH(k_persist_state_ops, gs, state_block(), c, qs);
+                evs.emplace_back(new RtEvent());
+                evs.back()->record();
+                stats.kernel_launches++;
+                stats.state_launches++;
+                for (int k : sub) { stats.state_tokens_per_round += hBlocks[k].tokCount; stats.state_bytes_per_round += hBlocks[k].uLen; }
+                if (gh > 0) {
+                    RT_LAUNCH2(k_persist_hdr_search, gh, 64, c, qh);
+                    stats.kernel_launches++;
+                }
+                RtEvent hsDone;
+                hsDone.record2();
+                rt_stream_wait(hsDone);
+                RT_LAUNCH(k_select, nA, state_block(), c, dResults);
+                stats.kernel_launches++;
+                stats.search_lanes = 1;
+            } else {
             // Split the active blocks into groups, one stream lane each: the launch tail of one group's level
             // (a few long recode/tree ops) overlaps the other groups' levels.
             int G = std::min(lanes(), std::max(1, nA / 16));
@@ -765,15 +856,16 @@ struct Batch {
                 stats.kernel_launches++;
                 laneDone.emplace_back(new RtEvent());
                 laneDone.back()->record();
+                stats.search_lanes = G;
             }
             rt().cur = 0;
             for (auto& ev : laneDone) rt_stream_wait(*ev);
+            }
             e1.record();
             std::vector<D4GRoundResult> r(sub.size());
             rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
             msSearch += rt_elapsed_ms(e0, e1);
             for (size_t k = 0; k + 1 < evs.size(); k += 2) stats.ms_state_kernels += rt_elapsed_ms(*evs[k], *evs[k + 1]);
-            stats.search_lanes = G;
             for (size_t k = 0; k < sub.size(); k++) {
                 res[subPos[k]] = r[k];
                 gpuType[sub[k]] = r[k].newType;

@@ -3,9 +3,27 @@
 #pragma once
 #include "d4g_device.h"
 
+// Candidate states and masks are handed from workgroup to workgroup inside one launch.  They are
+// written with agent-scope write-through stores and read with agent-scope (L1-bypassing) loads, so the
+// hand-off needs no L2 write-back / L1 invalidate per task (MI355X_MICROARCH.md: "sc1 stores + drained
+// flag", every load of the handed-off bytes an sc1 load).  Tokens and decoded bytes are read-only and
+// keep using plain cached loads.
+#ifdef D4G_HOSTSIM
+D4G_DEV uint32_t ld_sc1(const uint32_t* p) { return *p; }
+D4G_DEV uint64_t ld_sc1(const uint64_t* p) { return *p; }
+D4G_DEV void st_sc1(uint32_t* p, uint32_t v) { *p = v; }
+D4G_DEV void st_sc1(uint64_t* p, uint64_t v) { *p = v; }
+#else
+D4G_DEV uint32_t ld_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV uint64_t ld_sc1(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void st_sc1(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+D4G_DEV int ld_state_i32(const int32_t* p) { return (int)ld_sc1((const uint32_t*)p); }
+
+
 struct D4GCtx {
-    const uint32_t* tokA;
-    const uint32_t* tokOff;
+    const uint2* tok;         // {token word, decoded-byte offset}
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -28,9 +46,9 @@ struct D4GLds {
     D4GState st;
     long long red[32];
     int misc[64];
-    alignas(16) unsigned char treeLit[TreeMem<uint32_t, uint16_t, D4G_NLIT>::bytes(1)];
-    alignas(16) unsigned char treeDist[TreeMem<uint32_t, uint16_t, D4G_NDIST>::bytes(1)];
-    alignas(16) unsigned char treeCl[TreeMem<uint16_t, uint8_t, 20>::bytes(1)];
+    alignas(16) unsigned char treeLit[TreeMem<uint64_t, uint16_t, D4G_NLIT>::bytes(1)];
+    alignas(16) unsigned char treeDist[TreeMem<uint64_t, uint16_t, D4G_NDIST>::bytes(1)];
+    alignas(16) unsigned char treeCl[TreeMem<uint32_t, uint8_t, 20>::bytes(1)];
     uint16_t clFreq[20];
 };
 
@@ -40,20 +58,9 @@ D4G_DEV D4GState* state_ptr(const D4GCtx& c, int blockIdx_, int slot) { return c
 D4G_DEV void wg_copy_words(uint32_t* dst, const uint32_t* src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
-D4G_DEV void wg_load_state(D4GState* S, const D4GState* g) {
-    __syncthreads();
-    wg_copy_words((uint32_t*)S, (const uint32_t*)g, (int)(sizeof(D4GState) / 4));
-    __syncthreads();
-}
-D4G_DEV void wg_store_state(D4GState* g, const D4GState* S) {
-    __syncthreads();
-    wg_copy_words((uint32_t*)g, (const uint32_t*)S, (int)(sizeof(D4GState) / 4));
-    __syncthreads();
-}
-D4G_DEV void wg_copy_mask(uint64_t* dst, const uint64_t* src, long long words) {
-    for (long long i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-}
+D4G_DEV void wg_load_state(D4GState* S, const D4GState* g);
+D4G_DEV void wg_store_state(D4GState* g, const D4GState* S);
+D4G_DEV void wg_copy_mask(uint64_t* dst, const uint64_t* src, long long words);
 
 // Bits of one back-reference under the state's codes — getLitLenSize, DeflateBlockHuffman.java:112-131
 D4G_DEV int backref_cost(const D4GState* S, int len, int edge, int dist, int& lsym, int& dsym) {
@@ -100,17 +107,33 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     long long saved = 0;
     __syncthreads();
+    // software-pipelined: the next 64 tokens and their mask word are requested before the current ones are used
+    const uint2* tk = c.tok + b.tokStart;
+    uint2 ntok = make_uint2(0u, 0u);
+    uint64_t nmw = 0;
+    if (wave < b.maskWords) {
+        long long t = (long long)wave * 64 + lane;
+        if (t < b.tokCount) ntok = tk[t];
+        nmw = ld_sc1(maskIn + wave);
+    }
     for (long long w = wave; w < b.maskWords; w += nw) {
+        uint2 cur = ntok;
+        uint64_t mw = nmw;
         long long t = w * 64 + lane;
-        uint64_t mw = maskIn[w];
+        long long w2 = w + nw;
+        if (w2 < b.maskWords) {
+            long long t2 = w2 * 64 + lane;
+            ntok = t2 < b.tokCount ? tk[t2] : make_uint2(0u, 0u);
+            nmw = ld_sc1(maskIn + w2);
+        }
         int bit = (int)((mw >> lane) & 1);
         if (t < b.tokCount && !bit) {
-            uint32_t a = c.tokA[b.tokStart + t];
+            uint32_t a = cur.x;
             int dist = tok_dist(a);
             if (dist > 0) {
                 int len = tok_val(a), lsym, dsym;
                 int cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
-                const uint8_t* p = c.U + b.uBase + c.tokOff[b.tokStart + t];
+                const uint8_t* p = c.U + b.uBase + cur.y;
                 int total = 0;
                 bool ok = true;
                 for_bytes(p, len, [&](int b) {
@@ -130,7 +153,7 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
             }
         }
         uint64_t nm = __ballot(bit);
-        if (lane == 0) maskOut[w] = nm;
+        if (lane == 0) st_sc1(maskOut + w, nm);
     }
     saved = wg_sum_i64(saved, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
@@ -151,21 +174,36 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
     if (threadIdx.x < 4) flags[threadIdx.x] = 0;
     __syncthreads();
     if (S->type == D4G_DYNAMIC) {
+        const uint2* tk = c.tok + b.tokStart;
+        uint2 ntok = make_uint2(0u, 0u);
+        uint64_t nmw = 0;
+        if (wave < b.maskWords) {
+            long long t = (long long)wave * 64 + lane;
+            if (t < b.tokCount) ntok = tk[t];
+            nmw = ld_sc1(maskIn + wave);
+        }
         for (long long w = wave; w < b.maskWords; w += nw) {
+            uint2 cur = ntok;
+            uint64_t mw = nmw;
             long long t = w * 64 + lane;
-            uint64_t mw = maskIn[w];
+            long long w2 = w + nw;
+            if (w2 < b.maskWords) {
+                long long t2 = w2 * 64 + lane;
+                ntok = t2 < b.tokCount ? tk[t2] : make_uint2(0u, 0u);
+                nmw = ld_sc1(maskIn + w2);
+            }
             int len = 0, cost = 0, bin = 0;
             long long off = 0;
             bool act = false;
             if (t < b.tokCount && !((mw >> lane) & 1)) {
-                uint32_t a = c.tokA[b.tokStart + t];
+                uint32_t a = cur.x;
                 int dist = tok_dist(a);
                 if (dist > 0) {
                     int lsym, dsym;
                     len = tok_val(a);
                     cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
                     bin = lsym - 257;
-                    off = c.tokOff[b.tokStart + t];
+                    off = cur.y;
                     act = true;
                     atomicOr(&flags[1], 1u << bin);
                 }
@@ -218,15 +256,30 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
     }
     __syncthreads();
     int rem = (int)flags[2] - 1;
+    const uint2* tk2 = c.tok + b.tokStart;
+    uint2 ntok2 = make_uint2(0u, 0u);
+    uint64_t nmw2 = 0;
+    if (wave < b.maskWords) {
+        long long t = (long long)wave * 64 + lane;
+        if (t < b.tokCount) ntok2 = tk2[t];
+        nmw2 = ld_sc1(maskIn + wave);
+    }
     for (long long w = wave; w < b.maskWords; w += nw) {
+        uint2 cur = ntok2;
+        uint64_t mw = nmw2;
         long long t = w * 64 + lane;
-        uint64_t mw = maskIn[w];
+        long long w2 = w + nw;
+        if (w2 < b.maskWords) {
+            long long t2 = w2 * 64 + lane;
+            ntok2 = t2 < b.tokCount ? tk2[t2] : make_uint2(0u, 0u);
+            nmw2 = ld_sc1(maskIn + w2);
+        }
         int bit = (int)((mw >> lane) & 1);
         int len = 0;
         long long off = 0;
         bool hit = false;
         if (rem >= 0 && t < b.tokCount && !bit) {
-            uint32_t a = c.tokA[b.tokStart + t];
+            uint32_t a = cur.x;
             int dist = tok_dist(a);
             if (dist > 0) {
                 len = tok_val(a);
@@ -234,7 +287,7 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
                 if (lsym - 257 == rem) {
                     bit = 1;
                     hit = true;
-                    off = c.tokOff[b.tokStart + t];
+                    off = cur.y;
                     atomicSub(&S->hist[lsym], 1u);
                     atomicSub(&S->hist[D4G_NLIT + d4g_dist2sym(dist)], 1u);
                 }
@@ -252,7 +305,7 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
             for (int k = lane; k < l2; k += 64) atomicAdd(&S->hist[p2[k]], 1u);
         }
         uint64_t nm = __ballot(bit);
-        if (lane == 0) maskOut[w] = nm;
+        if (lane == 0) st_sc1(maskOut + w, nm);
     }
     __syncthreads();
 }
@@ -263,7 +316,7 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
 // code-length-code tree from L->clFreq — Huffman.ofRLEPacked, B/huffman/Huffman.java:117-134
 __device__ void t0_build_cl_tree(D4GLds* L) {
     D4GState* S = &L->st;
-    TreeMem<uint16_t, uint8_t, 20> tm;
+    TreeMem<uint32_t, uint8_t, 20> tm;
     tm.carve(L->treeCl, 1);
     for (int i = 0; i < 19; i++) S->clLen[i] = 0;
     int err = d4g_build_tree(tm, 1, 0, 19, 7, [&](int i) { return (unsigned)L->clFreq[i]; },
@@ -410,7 +463,7 @@ __device__ void wg_recode_huffman(D4GLds* L) {
     for (int i = threadIdx.x; i < D4G_NDIST; i += blockDim.x) S->distLen[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        TreeMem<uint32_t, uint16_t, D4G_NLIT> tm;
+        TreeMem<uint64_t, uint16_t, D4G_NLIT> tm;
         tm.carve(L->treeLit, 1);
         int err = d4g_build_tree(tm, 1, 0, lastLit, 15, [&](int i) { return S->hist[i]; },
                                  [&](int v, int len) { S->litLen[v] = (uint8_t)len; });
@@ -426,7 +479,7 @@ __device__ void wg_recode_huffman(D4GLds* L) {
             S->nDist = lastDist;
             S->distLen[lastDist - 1] = 1;
         } else {
-            TreeMem<uint32_t, uint16_t, D4G_NDIST> tm;
+            TreeMem<uint64_t, uint16_t, D4G_NDIST> tm;
             tm.carve(L->treeDist, 1);
             int err = d4g_build_tree(tm, 1, 0, lastDist, 15, [&](int i) { return S->hist[D4G_NLIT + i]; },
                                      [&](int v, int len) { S->distLen[v] = (uint8_t)len; });
@@ -462,6 +515,99 @@ __device__ void wg_recode_to_fixed(D4GLds* L) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Dependency-driven execution.  Instead of one launch per program level, persistent workgroups pull
+// (block, op) tasks from a queue ordered by level; an op waits for its source slot's ready flag and
+// publishes its own.  Tasks are pulled in queue order, so a task's producer was always pulled earlier
+// by a workgroup that is resident and running: waiting never deadlocks, whatever subset of the grid
+// is resident.  Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility): producer stores ->
+// every wave s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0 agent-scope release -> relaxed agent
+// flag store; consumer lane 0 relaxed agent poll -> agent-scope acquire -> barrier -> plain loads.
+// ---------------------------------------------------------------------------------------
+struct D4GQueue {
+    const int32_t* opFlat;   // op ids in level order
+    int32_t nOpsFlat;
+    unsigned* head;          // [8] next task index of each XCD's queue
+    int32_t* ready;          // [numBlocks * slotsPerBlock]: epoch in which the slot was last produced
+    int32_t epoch;
+    int32_t xoff[9];         // the active list is grouped by XCD: group x = active[xoff[x], xoff[x+1])
+};
+
+// Pull the next task: first from the queue of this workgroup's XCD (workgroup ids equal mod 8 share an XCD
+// and its L2, so a deflate block's tokens and decoded bytes stay in one L2), then steal from the others.
+// Returns false when every queue is empty.  Thread 0 only.
+D4G_DEV bool d4g_pull_task(const D4GQueue& q, int& cursor, int& opIdx, int& actIdx) {
+    for (; cursor < 8; cursor++) {
+        int x = (int)((blockIdx.x + cursor) & 7);
+        int nA = q.xoff[x + 1] - q.xoff[x];
+        long long nTasks = (long long)q.nOpsFlat * nA;
+        if (nTasks == 0) continue;
+        long long t = atomicAdd(q.head + x, 1u);
+        if (t < nTasks) {
+            opIdx = (int)(t / nA);
+            actIdx = q.xoff[x] + (int)(t % nA);
+            return true;
+        }
+    }
+    return false;
+}
+
+#ifdef D4G_HOSTSIM
+D4G_DEV int d4g_flag_load(const int32_t* p) { return *p; }
+D4G_DEV void d4g_flag_store(int32_t* p, int v) { *p = v; }
+D4G_DEV void d4g_release_agent() {}
+D4G_DEV void d4g_acquire_agent() {}
+D4G_DEV void d4g_drain_stores() {}
+D4G_DEV void d4g_sleep() {}
+#else
+D4G_DEV int d4g_flag_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void d4g_flag_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void d4g_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(8); }
+#endif
+
+D4G_DEV void wg_load_state(D4GState* S, const D4GState* g) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)(sizeof(D4GState) / 4); i += blockDim.x) ((uint32_t*)S)[i] = ld_sc1((const uint32_t*)g + i);
+    __syncthreads();
+}
+D4G_DEV void wg_store_state(D4GState* g, const D4GState* S) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)(sizeof(D4GState) / 4); i += blockDim.x) st_sc1((uint32_t*)g + i, ((const uint32_t*)S)[i]);
+    __syncthreads();
+}
+D4G_DEV void wg_copy_mask(uint64_t* dst, const uint64_t* src, long long words) {
+    for (long long i = threadIdx.x; i < words; i += blockDim.x) st_sc1(dst + i, ld_sc1(src + i));
+    __syncthreads();
+}
+
+// All threads call.  Returns false if the slot never became ready (bounded spin; counted as a device error).
+__device__ bool wg_wait_slot(const D4GCtx& c, const D4GQueue& q, int blk, int slot, int* lds) {
+    if (slot == 0) return true;  // the block's current state was written by an earlier kernel
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int32_t* f = q.ready + (long long)blk * c.slotsPerBlock + slot;
+        int ok = 0;
+        // bounded: ~1 s in total, and every waiter gives up as soon as any other has failed
+        for (long long spin = 0; spin < (1LL << 21); spin++) {
+            if (d4g_flag_load(f) == q.epoch) { ok = 1; break; }
+            if ((spin & 63) == 63 && d4g_flag_load(c.errors) != 0) break;
+            d4g_sleep();
+        }
+        if (!ok) atomicAdd(c.errors, 1);
+        *lds = ok;
+    }
+    __syncthreads();
+    return *lds != 0;
+}
+__device__ void wg_publish_slot(const D4GCtx& c, const D4GQueue& q, int blk, int slot) {
+    d4g_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) d4g_flag_store(q.ready + (long long)blk * c.slotsPerBlock + slot, q.epoch);
+}
+
+// ---------------------------------------------------------------------------------------
 // State-op executor: one workgroup = one op of the program on one block.
 // ---------------------------------------------------------------------------------------
 __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId) {
@@ -474,12 +620,15 @@ __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId)
     const D4GState* src = state_ptr(c, blk, op.src);
     long long* keyp = c.keys + (long long)blk * c.nOps + opId;
     if (op.kind == OP_CAND) {
-        if (threadIdx.x == 0) *keyp = src->valid ? D4G_MAKE_KEY(src->sizeBits, (long long)opId * 64) : D4G_KEY_NONE;
+        if (threadIdx.x == 0) {
+            long long sz = (long long)ld_sc1((const uint64_t*)&src->sizeBits);
+            *keyp = ld_state_i32(&src->valid) ? D4G_MAKE_KEY(sz, (long long)opId * 64) : D4G_KEY_NONE;
+        }
         return;
     }
     D4GState* dst = state_ptr(c, blk, op.dst);
-    if (!src->valid) {  // the reference never builds this candidate (null / skipped branch)
-        if (threadIdx.x == 0) { dst->valid = 0; *keyp = D4G_KEY_NONE; }
+    if (!ld_state_i32(&src->valid)) {  // the reference never builds this candidate (null / skipped branch)
+        if (threadIdx.x == 0) { st_sc1((uint32_t*)&dst->valid, 0u); *keyp = D4G_KEY_NONE; }
         return;
     }
     wg_load_state(S, src);
@@ -488,8 +637,22 @@ __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId)
     case OP_OPT: {
         long long orig = S->sizeBits;
         uint64_t* mo = mask_ptr(c, b, op.maskSlot);
+#ifdef D4G_PROFILE_OPS
+        long long tA = clock64();
+#endif
         wg_replace_backrefs(L, c, b, maskIn, mo, false);
+#ifdef D4G_PROFILE_OPS
+        long long tB = clock64();
+#endif
         wg_optimise_header(L);
+#ifdef D4G_PROFILE_OPS
+        if (threadIdx.x == 0 && c.opStats) {
+            atomicAdd((unsigned long long*)&c.opStats[20], (unsigned long long)(tA - tStart));
+            atomicAdd((unsigned long long*)&c.opStats[21], (unsigned long long)(tB - tA));
+            atomicAdd((unsigned long long*)&c.opStats[22], (unsigned long long)(clock64() - tB));
+            atomicAdd((unsigned long long*)&c.opStats[23], 1ULL);
+        }
+#endif
         if (threadIdx.x == 0) {
             S->maskSlot = op.maskSlot;
             S->valid = (op.arg & 1) ? (orig - S->sizeBits > 0) : 1;
@@ -591,6 +754,33 @@ __global__ void __launch_bounds__(256) k_exec_state_ops(D4GCtx c, const int32_t*
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
+__global__ void __launch_bounds__(256) k_persist_state_ops(D4GCtx c, D4GQueue q) {
+    __shared__ D4GLds L;
+    __shared__ int sTask[3], sOk;
+    int cursor = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int oi = 0, ai = 0;
+            sTask[0] = d4g_pull_task(q, cursor, oi, ai) ? 1 : 0;
+            sTask[1] = oi;
+            sTask[2] = ai;
+        }
+        __syncthreads();
+        if (!sTask[0]) break;
+        int opId = q.opFlat[sTask[1]];
+        int blk = c.active[sTask[2]];
+        const D4GOp op = c.ops[opId];
+        bool ok = wg_wait_slot(c, q, blk, op.src, &sOk);
+        if (ok) d4g_exec_state_op(&L, c, blk, opId);
+        else if (threadIdx.x == 0) {
+            c.keys[(long long)blk * c.nOps + opId] = D4G_KEY_NONE;
+            if (op.dst >= 0) st_sc1((uint32_t*)&state_ptr(c, blk, op.dst)->valid, 0u);
+        }
+        if (op.dst >= 0) wg_publish_slot(c, q, blk, op.dst);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Header search: the 56 optimiseBlockDynBlock candidates of one base block, one lane each.
 // DeflateStream.java:184-198 (rewriteHeader(flags) -> [recodeHeaderToLessRLEMatches] ->
@@ -599,17 +789,18 @@ __global__ void __launch_bounds__(256) k_exec_state_ops(D4GCtx c, const int32_t*
 // keeps only the 19 symbol counts, two code-length-code tables and its tree scratch in LDS.
 // ---------------------------------------------------------------------------------------
 struct D4GHdrLds {
+    alignas(16) uint8_t lens[D4G_NLIT + D4G_NDIST];
     uint8_t runV[D4G_MAXPAIRS];
     uint16_t runL[D4G_MAXPAIRS];
     int nRuns;
-    alignas(16) unsigned char tree[TreeMem<uint16_t, uint8_t, 20>::bytes(64)];
+    alignas(16) unsigned char tree[TreeMem<uint32_t, uint8_t, 20>::bytes(64)];
     uint16_t freq[19 * 64];
     uint8_t cl0[19 * 64];
     uint8_t cl1[19 * 64];
 };
 
 __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits) {
-    TreeMem<uint16_t, uint8_t, 20> tm;
+    TreeMem<uint32_t, uint8_t, 20> tm;
     tm.carve(H->tree, 64);
 #define FQ(s) H->freq[(s) * 64 + lane]
 #define C0(s) H->cl0[(s) * 64 + lane]
@@ -665,24 +856,23 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
     return litlenBits + hdr;
 }
 
-__global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {
-    __shared__ D4GHdrLds H;
-    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
-    int bs, orel;
-    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
-    int blk = c.active[bs];
-    int opId = opList[orel];
+__device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c, int blk, int opId) {
     const D4GOp op = c.ops[opId];
     const D4GState* base = state_ptr(c, blk, op.src);
     long long* keyp = c.keys + (long long)blk * c.nOps + opId;
-    int lane = threadIdx.x;
-    if (!base->valid || base->type != D4G_DYNAMIC) {
+    int lane = threadIdx.x & 63;
+    __syncthreads();
+    if (!ld_state_i32(&base->valid) || ld_state_i32(&base->type) != D4G_DYNAMIC) {
         if (lane == 0) *keyp = D4G_KEY_NONE;
         return;
     }
-    int nLit = base->nLit, n = base->nLit + base->nDist;
-    for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? base->litLen[i] : base->distLen[i - nLit];
+    int nLit = ld_state_i32(&base->nLit), n = nLit + ld_state_i32(&base->nDist);
+    // code lengths word by word (litLen and distLen are 4-byte aligned, contiguous in the state)
+    for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) ((uint32_t*)H.lens)[i] = ld_sc1((const uint32_t*)base->litLen + i);
     __syncthreads();
+    for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? H.lens[i] : H.lens[D4G_NLIT + i - nLit];
+    __syncthreads();
+    long long baseLitlenBits = (long long)ld_sc1((const uint64_t*)&base->litlenBits);
     if (lane == 0) {
         int nr = 0;
         d4g_for_runs(n, [&](int i) { return (int)comb[i]; }, [&](int v, int r) { H.runV[nr] = (uint8_t)v; H.runL[nr] = (uint16_t)r; nr++; });
@@ -691,11 +881,42 @@ __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t*
     __syncthreads();
     long long key = D4G_KEY_NONE;
     if (lane < 56) {
-        long long size = d4g_hdr_candidate(&H, lane, c.hdrFlags[lane], c.hdrPrune[lane], base->litlenBits);
+        long long size = d4g_hdr_candidate(&H, lane, c.hdrFlags[lane], c.hdrPrune[lane], baseLitlenBits);
         key = D4G_MAKE_KEY(size, (long long)opId * 64 + lane);
     }
     key = wave_min_i64(key);
     if (lane == 0) *keyp = key;
+}
+
+__global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+    __shared__ D4GHdrLds H;
+    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
+    int bs, orel;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    d4g_exec_hdr_search(H, comb, c, c.active[bs], opList[orel]);
+}
+
+__global__ void __launch_bounds__(64) k_persist_hdr_search(D4GCtx c, D4GQueue q) {
+    __shared__ D4GHdrLds H;
+    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
+    __shared__ int sTask[3], sOk;
+    int cursor = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int oi = 0, ai = 0;
+            sTask[0] = d4g_pull_task(q, cursor, oi, ai) ? 1 : 0;
+            sTask[1] = oi;
+            sTask[2] = ai;
+        }
+        __syncthreads();
+        if (!sTask[0]) break;
+        int opId = q.opFlat[sTask[1]];
+        int blk = c.active[sTask[2]];
+        bool ok = wg_wait_slot(c, q, blk, c.ops[opId].src, &sOk);
+        if (ok) d4g_exec_hdr_search(H, comb, c, blk, opId);
+        else if (threadIdx.x == 0) c.keys[(long long)blk * c.nOps + opId] = D4G_KEY_NONE;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

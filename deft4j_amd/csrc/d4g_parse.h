@@ -47,7 +47,7 @@ struct D4GEmitIn {
     int32_t stream;
     int32_t type;
     long long bitPos;
-    long long tokStart;    // absolute index into tokA/tokOff
+    long long tokStart;    // absolute index into tok
     long long uStart;      // stream-relative offset of the block's decoded bytes
     long long uLen;
     long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
@@ -244,8 +244,7 @@ __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* strea
 // EMIT = true writes tokens and the block's initial state.
 // ---------------------------------------------------------------------------------------
 struct D4GParseOut {
-    uint32_t* tokA;
-    uint32_t* tokOff;
+    uint2* tok;
     uint8_t* U;
     D4GState* states;
 };
@@ -441,8 +440,8 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                 }
                 litlenBits += used;
                 if (EMIT) {
-                    out.tokA[em->tokStart + nTok] = (uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16);
-                    out.tokOff[em->tokStart + nTok] = (uint32_t)(em->uStart + nU);
+                    out.tok[em->tokStart + nTok] = make_uint2((uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16),
+                                                              (uint32_t)(em->uStart + nU));
                 }
                 nTok++;
                 if (sym == 256) { code = 1; break; }
@@ -482,7 +481,7 @@ __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* stream
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
-    D4GParseOut none = {nullptr, nullptr, nullptr, nullptr};
+    D4GParseOut none = {nullptr, nullptr, nullptr};
     d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
     if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
 }
@@ -500,8 +499,8 @@ __global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams
 // ---------------------------------------------------------------------------------------
 struct D4GTokRange { int32_t stream; int32_t stored; long long tokStart, tokCount, uStart, uLen; };
 
-__global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, const D4GTokRange* ranges, const uint32_t* tokA,
-                                                  const uint32_t* tokOff, uint8_t* U, uint32_t* src, int32_t* badDist, int G) {
+__global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, const D4GTokRange* ranges, const uint2* tok,
+                                                  uint8_t* U, uint32_t* src, int32_t* badDist, int G) {
     const D4GTokRange r = ranges[blockIdx.x / G];
     const D4GStreamDesc sd = streams[r.stream];
     uint32_t* s = src + sd.uBase;
@@ -513,8 +512,8 @@ __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, 
         return;
     }
     for (long long t = t0; t < r.tokCount; t += stride) {
-        uint32_t a = tokA[r.tokStart + t];
-        uint32_t pos = tokOff[r.tokStart + t];
+        uint2 tk = tok[r.tokStart + t];
+        uint32_t a = tk.x, pos = tk.y;
         int dist = tok_dist(a), val = tok_val(a);
         if (dist == 0) {
             if (val < 256) { u[pos] = (uint8_t)val; s[pos] = pos; }

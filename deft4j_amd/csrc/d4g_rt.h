@@ -67,6 +67,11 @@ inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().a[rt(
         hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().b[rt().cur], __VA_ARGS__); \
         RT_CHECK(hipGetLastError());                                                                \
     } while (0)
+inline int device_cus() {
+    hipDeviceProp_t prop;
+    RT_CHECK(hipGetDeviceProperties(&prop, rt().device < 0 ? 0 : rt().device));
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
 inline float rt_elapsed_ms(RtEvent& a, RtEvent& b) {
     RT_CHECK(hipEventSynchronize(b.e));
     float ms = 0;

@@ -6,9 +6,10 @@
 // *RLE pairs* (DeflateBlockHuffman.java:43).  A candidate encoding of a block is a *state*.
 //
 // HBM layout (all arrays live in device memory for the whole call):
-//   tokA[t]   u32  literal byte | 256 (EOB) | match length, dist << 16 (0 for literals/EOB),
-//                  bit 15 = the 284-as-258 edge case (DeflateBlockHuffman.java:843)
-//   tokOff[t] u32  offset of the token's decoded bytes in U (the stream's decoded data)
+//   tok[t]    2 x u32 (one 8-byte load per token):
+//             .x  literal byte | 256 (EOB) | match length, dist << 16 (0 for literals/EOB),
+//                 bit 15 = the 284-as-258 edge case (DeflateBlockHuffman.java:843)
+//             .y  offset of the token's decoded bytes in U (the stream's decoded data)
 //   U[]       u8   decoded bytes of the whole stream, block after block
 //   State     ~3.3 KB per candidate: code lengths, header RLE pairs, symbol histogram, sizes
 //   masks     1 bit per token: "this back-reference is expanded to literals".  The reference
@@ -52,7 +53,7 @@ struct D4GState {
 struct D4GBlock {
     int32_t type;        // D4G_STORED / FIXED / DYNAMIC
     int32_t stream;      // owning stream
-    int64_t tokStart;    // first token (index into tokA/tokOff); tokCount includes the final EOB
+    int64_t tokStart;    // first token (index into tok); tokCount includes the final EOB
     int64_t tokCount;
     int64_t uBase;       // start of the owning stream's region in U (tokOff values are relative to it)
     int64_t uStart;      // decoded bytes [uStart, uStart+uLen) of the stream's region

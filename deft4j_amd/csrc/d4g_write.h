@@ -128,17 +128,19 @@ __global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs
     for (long long t0 = 0; t0 < b.tokCount; t0 += blockDim.x) {
         long long t = t0 + threadIdx.x;
         long long nbits = 0;
-        uint32_t a = 0;
+        uint32_t a = 0, toff = 0;
         int kind = 0;  // 0 none, 1 single symbol, 2 back-reference, 3 expanded back-reference
         if (t < b.tokCount) {
-            a = c.tokA[b.tokStart + t];
+            uint2 tkw = c.tok[b.tokStart + t];
+            a = tkw.x;
+            toff = tkw.y;
             int dist = tok_dist(a), val = tok_val(a);
             if (dist == 0) {
                 if (val == 256 && t != b.tokCount - 1) kind = 0;  // EOB of a merged-away block
                 else { kind = 1; nbits = S->litLen[val]; }
             } else if ((mask[t >> 6] >> (t & 63)) & 1) {
                 kind = 3;
-                const uint8_t* p = Ub + c.tokOff[b.tokStart + t];
+                const uint8_t* p = Ub + toff;
                 for_bytes(p, val, [&](int by) { nbits += S->litLen[by]; return true; });
             } else {
                 kind = 2;
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs
             put_bits(out, pos, bits, n);
         } else if (kind == 3) {
             int len = tok_val(a);
-            const uint8_t* p = Ub + c.tokOff[b.tokStart + t];
+            const uint8_t* p = Ub + toff;
             for_bytes(p, len, [&](int by) {
                 int l = S->litLen[by];
                 put_bits(out, pos, W.litCode[by], l);

@@ -17,6 +17,8 @@ buf = (ctypes.c_longlong * 64)()
 L.d4g_debug_opstats(buf)
 names = {1: "OPT", 2: "RECODE", 3: "FULL", 4: "LEAST", 5: "POST", 6: "PRUNEHDR", 7: "TOFIXED"}
 print("ms_optimise %.1f state_ms %.1f" % (st["ms_optimise"], st["ms_state_kernels"]))
+if buf[23]:
+    print("OPT sections (mean cycles): load %.0f  token pass %.0f  optimise_header %.0f" % (buf[20] / buf[23], buf[21] / buf[23], buf[22] / buf[23]))
 for arg in (0, 1):
     for k, nm in names.items():
         cyc, n = buf[k * 2 + arg * 32], buf[k * 2 + 1 + arg * 32]

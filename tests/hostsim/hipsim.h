@@ -33,6 +33,8 @@
 struct SimDim3 { unsigned x, y, z; };
 extern SimDim3 threadIdx, blockIdx, blockDim, gridDim;
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 
 namespace hipsim {
 enum { READY = 0, AT_BARRIER = 1, AT_COLLECTIVE = 2, DONE = 3 };
@@ -130,6 +132,7 @@ struct RtEvent { void record() {} void record2() {} };  // timing is meaningless
 inline void rt_stream2_wait(RtEvent&) {}
 inline void rt_stream_wait(RtEvent&) {}
 inline float rt_elapsed_ms(RtEvent&, RtEvent&) { return 0.f; }
+inline int device_cus() { return 2; }
 #define RT_CHECK(x) (x)
 #define RT_LAUNCH2(kern, grid, block, ...) RT_LAUNCH(kern, grid, block, __VA_ARGS__)
 #define RT_LAUNCH(kern, grid, block, ...) (hipsim::sim().kname = #kern, hipsim::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kern(__VA_ARGS__); }))
