@@ -101,59 +101,87 @@ D4G_DEV void for_bytes(const uint8_t* p, int len, Fn fn) {
 // One lane per token, 64 tokens per wave step; the new mask word is the wave ballot.
 // The histogram follows the token list (back-reference symbols out, literal bytes in).
 // ---------------------------------------------------------------------------------------
+#define D4G_TOK_ILP 4  // tokens per lane per step: four independent dependency chains hide LDS / L2 latency
 __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
                                     bool prune) {
     D4GState* S = &L->st;
+    const int K = D4G_TOK_ILP;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     long long saved = 0;
     __syncthreads();
-    // software-pipelined: the next 64 tokens and their mask word are requested before the current ones are used
     const uint2* tk = c.tok + b.tokStart;
-    uint2 ntok = make_uint2(0u, 0u);
-    uint64_t nmw = 0;
-    if (wave < b.maskWords) {
-        long long t = (long long)wave * 64 + lane;
-        if (t < b.tokCount) ntok = tk[t];
-        nmw = ld_sc1(maskIn + wave);
-    }
-    for (long long w = wave; w < b.maskWords; w += nw) {
-        uint2 cur = ntok;
-        uint64_t mw = nmw;
-        long long t = w * 64 + lane;
-        long long w2 = w + nw;
-        if (w2 < b.maskWords) {
-            long long t2 = w2 * 64 + lane;
-            ntok = t2 < b.tokCount ? tk[t2] : make_uint2(0u, 0u);
-            nmw = ld_sc1(maskIn + w2);
+    const uint8_t* Ub = c.U + b.uBase;
+    for (long long w0 = (long long)wave * K; w0 < b.maskWords; w0 += (long long)nw * K) {
+        uint2 tokv[K];
+        uint64_t mwv[K];
+        // stage A: K token vectors and mask words in flight together
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            long long w = w0 + j, t = w * 64 + lane;
+            tokv[j] = (w < b.maskWords && t < b.tokCount) ? tk[t] : make_uint2(0u, 0u);
+            mwv[j] = w < b.maskWords ? ld_sc1(maskIn + w) : 0;
         }
-        int bit = (int)((mw >> lane) & 1);
-        if (t < b.tokCount && !bit) {
-            uint32_t a = cur.x;
+        int bit[K], len[K], cost[K], total[K], cnt[K], have[K], lsym[K], dsym[K];
+        bool undec[K], ok[K];
+        const uint32_t* wp[K];
+        uint32_t cur[K], nxt[K];
+        // stage B: costs (LDS lookups of K tokens overlap), stage C: first two words of each token's bytes
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            bit[j] = (int)((mwv[j] >> lane) & 1);
+            uint32_t a = tokv[j].x;
             int dist = tok_dist(a);
-            if (dist > 0) {
-                int len = tok_val(a), lsym, dsym;
-                int cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
-                const uint8_t* p = c.U + b.uBase + cur.y;
-                int total = 0;
-                bool ok = true;
-                for_bytes(p, len, [&](int b) {
-                    int bs = S->litLen[b];
-                    if (bs < 1) { ok = false; return false; }
-                    total += bs;
-                    if (prune ? total > cost : total >= cost) { ok = false; return false; }
-                    return true;
-                });
-                if (ok) {
-                    bit = 1;
-                    saved += cost - total;
-                    atomicSub(&S->hist[lsym], 1u);
-                    atomicSub(&S->hist[D4G_NLIT + dsym], 1u);
-                    for_bytes(p, len, [&](int b) { atomicAdd(&S->hist[b], 1u); return true; });
+            undec[j] = dist > 0 && !bit[j];
+            ok[j] = undec[j];
+            len[j] = tok_val(a);
+            total[j] = 0;
+            cnt[j] = 0;
+            cost[j] = 0;
+            lsym[j] = dsym[j] = 0;
+            cur[j] = nxt[j] = 0;
+            have[j] = 0;
+            wp[j] = nullptr;
+            if (undec[j]) {
+                cost[j] = backref_cost(S, len[j], tok_edge(a), dist, lsym[j], dsym[j]);
+                uintptr_t ad = (uintptr_t)(Ub + tokv[j].y);
+                wp[j] = (const uint32_t*)(ad & ~(uintptr_t)3);
+                int skip = (int)(ad & 3);
+                cur[j] = *wp[j]++ >> (8 * skip);
+                have[j] = 4 - skip;
+                nxt[j] = *wp[j]++;  // U is padded: reading one word past a short token is harmless
+            }
+        }
+        // stage D: the K early-exit literal sums advance in lock step, one byte each per turn
+        while (undec[0] | undec[1] | undec[2] | undec[3]) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                if (undec[j]) {
+                    if (have[j] == 0) { cur[j] = nxt[j]; have[j] = 4; nxt[j] = *wp[j]++; }
+                    int bs = S->litLen[cur[j] & 0xff];
+                    cur[j] >>= 8;
+                    have[j]--;
+                    if (bs < 1) { ok[j] = false; undec[j] = false; }
+                    else {
+                        total[j] += bs;
+                        if (prune ? total[j] > cost[j] : total[j] >= cost[j]) { ok[j] = false; undec[j] = false; }
+                        else if (++cnt[j] == len[j]) undec[j] = false;
+                    }
                 }
             }
         }
-        uint64_t nm = __ballot(bit);
-        if (lane == 0) st_sc1(maskOut + w, nm);
+        // stage E: apply, stage F: new mask words
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            if (ok[j]) {
+                bit[j] = 1;
+                saved += cost[j] - total[j];
+                atomicSub(&S->hist[lsym[j]], 1u);
+                atomicSub(&S->hist[D4G_NLIT + dsym[j]], 1u);
+                for_bytes(Ub + tokv[j].y, len[j], [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
+            }
+            uint64_t nm = __ballot(bit[j]);
+            if (lane == 0 && w0 + j < b.maskWords) st_sc1(maskOut + w0 + j, nm);
+        }
     }
     saved = wg_sum_i64(saved, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }

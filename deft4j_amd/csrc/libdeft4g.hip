@@ -221,6 +221,12 @@ void d4g_free(void* p) { free(p); }
 
 #ifdef D4G_PROFILE_OPS
 // profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
+int d4g_debug_set_experiment(long long mode) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    rt_h2d(engine().dOpStats + 63, &mode, 8);
+    rt_sync();
+    return 0;
+}
 int d4g_debug_opstats(long long* out64) {
     std::lock_guard<std::mutex> lk(g_mu);
     rt_d2h(out64, engine().dOpStats, 64 * 8);

@@ -10,9 +10,15 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-ar
 import deft4j_amd as D, synth
 L = D.load_library(so); D.init(0, lib=L)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+exp = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+L.d4g_debug_set_experiment.argtypes = [ctypes.c_longlong]
+L.d4g_debug_set_experiment(exp)
 s = synth.make_stream(mib << 20)
 for it in range(2):
-    b = D.Batch([s], lib=L).run(False); st = b.stats(); b.close()
+    try:
+        b = D.Batch([s], lib=L).run(False); st = b.stats(); b.close()
+    except RuntimeError as e:
+        print('run error (expected in experiments):', str(e)[:80])
 buf = (ctypes.c_longlong * 64)()
 L.d4g_debug_opstats(buf)
 names = {1: "OPT", 2: "RECODE", 3: "FULL", 4: "LEAST", 5: "POST", 6: "PRUNEHDR", 7: "TOFIXED"}
