@@ -116,3 +116,25 @@ def test_full_size_properties(D):
     assert b2.result(0)["saved_bits"] >= 0
     assert zlib.decompress(b2.output(0), -15) == raw
     b2.close()
+
+
+def test_batch_of_independent_members(D):
+    """BASELINE config-3-shaped batch, scaled (64 x 256 KiB members instead of 1024 x 1 MiB): every stream
+    round-trips, the batch result equals the one-by-one result (streams are independent,
+    K/DeflateFilesContainer.java:22), and two members are checked bit for bit against the oracle."""
+    raws = [synth.reptext(256 << 10, 0xD4F7 + i) for i in range(64)]
+    ins = [synth.deflate9(r) for r in raws]
+    b = D.Batch(ins).run(True)
+    outs = [b.output(i) for i in range(len(ins))]
+    saved = [b.result(i)["saved_bits"] for i in range(len(ins))]
+    b.close()
+    for r, o in zip(raws, outs):
+        assert zlib.decompress(o, -15) == r
+    for i in (0, 37):
+        rc, want, sv, _, _ = O.optimise(ins[i], True)
+        assert outs[i] == want and saved[i] == sv
+    one = D.Batch([ins[5]]).run(True)
+    assert one.output(0) == outs[5] and one.result(0)["saved_bits"] == saved[5]
+    one.close()
+    total, outs2 = D.DeflateFilesContainer.optimise(ins[:4], True)
+    assert outs2 == outs[:4] and total == sum(saved[:4])
