@@ -29,11 +29,11 @@ class d4g_stats(ctypes.Structure):
                [("ms_search_kernels", ctypes.c_double), ("ms_parse_kernels", ctypes.c_double)] + \
                [(n, ctypes.c_int64) for n in ("scan_candidates", "scan_confirmed", "exact_probes", "jump_rounds")] + \
                [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64), ("state_tokens_per_round", ctypes.c_int64),
-                ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64)]
+                ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64), ("ms_checksum_kernels", ctypes.c_double)]
 
 
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",
-           "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
+           "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_checksums", "d4g_batch_parse", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
            "d4g_size_bits_fallback", "d4g_inflate", "d4g_free"]
 
 
@@ -64,6 +64,11 @@ def load_library(path=None):
     L.d4g_batch_copy_decoded.restype = ctypes.c_int
     L.d4g_batch_copy_decoded.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_batch_checksums.restype = ctypes.c_int
+    L.d4g_batch_checksums.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                      ctypes.POINTER(ctypes.c_int64)]
+    L.d4g_batch_parse.restype = ctypes.c_int
+    L.d4g_batch_parse.argtypes = [ctypes.c_void_p]
     L.d4g_batch_stats.restype = ctypes.c_int
     L.d4g_batch_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(d4g_stats)]
     L.d4g_batch_destroy.restype = None
@@ -146,6 +151,23 @@ class Batch:
         if rc != 0:
             raise RuntimeError(self.L.d4g_last_error().decode())
         return buf.raw[:n.value]
+
+    def parse(self):
+        """DeflateStream.parse for every stream (no optimisation); decoded bytes and checksums become available."""
+        rc = self.L.d4g_batch_parse(self.h)
+        if rc != 0:
+            raise RuntimeError("d4g_batch_parse: " + self.L.d4g_last_error().decode())
+        return self
+
+    def checksums(self, i):
+        """-> (crc32, adler32, isize) of stream i's decoded bytes, computed on the device."""
+        c = ctypes.c_uint32()
+        a = ctypes.c_uint32()
+        n = ctypes.c_int64()
+        rc = self.L.d4g_batch_checksums(self.h, i, ctypes.byref(c), ctypes.byref(a), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError(self.L.d4g_last_error().decode())
+        return c.value, a.value, n.value
 
     def stats(self):
         st = d4g_stats()

@@ -349,6 +349,7 @@ struct Engine {  // per-process device objects shared by all batches
     uint8_t* dHdrTables = nullptr;  // flags[64] + prune[64]
     int32_t* dErrors = nullptr;
     long long* dOpStats = nullptr;
+    uint32_t* dCrcTab = nullptr;   // [1024] slice-by-4 CRC-32 tables, then [32] x^(2^k) mod P
     int slotsPerBlock = 0, masksPerBlock = 0, maxOps = 0;
     bool ready = false;
     void init() {
@@ -366,6 +367,30 @@ struct Engine {  // per-process device objects shared by all batches
         rt_memset(dErrors, 0, 4);
         dOpStats = (long long*)rt_malloc(64 * 8);
         rt_memset(dOpStats, 0, 64 * 8);
+        {
+            std::vector<uint32_t> t(1024 + 32);
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+                t[i] = c;
+            }
+            for (int k = 1; k < 4; k++)
+                for (uint32_t i = 0; i < 256; i++) t[k * 256 + i] = (t[(k - 1) * 256 + i] >> 8) ^ t[t[(k - 1) * 256 + i] & 0xff];
+            auto mul = [](uint32_t a, uint32_t b) {
+                uint32_t m = 1u << 31, p = 0;
+                for (;;) {
+                    if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+                    m >>= 1;
+                    b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+                }
+                return p;
+            };
+            uint32_t p = 1u << 30;  // x^1
+            t[1024] = p;
+            for (int k = 1; k < 32; k++) t[1024 + k] = p = mul(p, p);
+            dCrcTab = (uint32_t*)rt_malloc(t.size() * 4);
+            rt_h2d(dCrcTab, t.data(), t.size() * 4);
+        }
         rt_sync();
         slotsPerBlock = std::max(progDyn.nSlots, progFixed.nSlots);
         masksPerBlock = std::max(progDyn.nMasks, progFixed.nMasks);
@@ -1133,6 +1158,34 @@ struct Batch {
         check_device_errors();
         for (HStream& s : streams)
             if (s.status == 0) stats.bytes_out += (s.outBits + 7) / 8;
+    }
+
+    // ---- trailer checksums of the decoded bytes (gzip CRC-32 + ISIZE, zlib Adler-32) ----
+    std::vector<D4GCsumOut> csums;
+    void checksums() {
+        if (!csums.empty() || streams.empty()) return;
+        if (!dU) throw std::runtime_error("checksums: the batch has not been parsed");
+        size_t n = streams.size();
+        std::vector<long long> base(n + 1, 0);
+        for (size_t i = 0; i < n; i++) base[i + 1] = base[i] + (streams[i].status == 0 ? (streams[i].nU + D4G_CSUM_TILE - 1) / D4G_CSUM_TILE : 0);
+        long long nTiles = base[n];
+        long long* dBase = (long long*)rt_malloc((n + 1) * 8);
+        rt_h2d(dBase, base.data(), (n + 1) * 8);
+        D4GCsumRec* dCh = (D4GCsumRec*)rt_malloc((size_t)nTiles * sizeof(D4GCsumRec) + 16);
+        D4GCsumOut* dOutC = (D4GCsumOut*)rt_malloc(n * sizeof(D4GCsumOut));
+        RtEvent e0, e1;
+        e0.record();
+        if (nTiles) {
+            RT_LAUNCH(k_csum_tiles, nTiles, 256, dStreams, dBase, (int)n, dU, engine().dCrcTab, dCh);
+            stats.kernel_launches++;
+        }
+        RT_LAUNCH(k_csum_combine, n, 256, dStreams, dBase, dCh, engine().dCrcTab + 1024, dOutC);
+        stats.kernel_launches++;
+        e1.record();
+        csums.resize(n);
+        rt_d2h(csums.data(), dOutC, n * sizeof(D4GCsumOut));
+        stats.ms_checksum_kernels = rt_elapsed_ms(e0, e1);
+        rt_free(dBase); rt_free(dCh); rt_free(dOutC);
     }
 
     void run(bool merge) {

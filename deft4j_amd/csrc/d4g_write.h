@@ -243,3 +243,146 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
     if (threadIdx.x == 0) { S->maskSlot = 0; S->valid = 1; S->flags = 0; }
     wg_store_state(state_ptr(c, job.blkM, 0), S);
 }
+
+// ---------------------------------------------------------------------------------------
+// Trailer checksums over the decoded bytes: CRC-32 + ISIZE for gzip members
+// (K/GZFile.java:129-145, java.util.zip.CRC32) and Adler-32 for zlib streams (K/ZLibFile.java:41-51).
+// k_csum_tiles: one workgroup per 128 KiB tile; thread t checksums 512 bytes (slice-by-4 CRC tables in
+// LDS, 16-byte loads), then the 256 results are concatenated pairwise in order;
+// k_csum_combine: one workgroup per stream folds the tile records in order.  Concatenation uses zlib's
+// algebra: CRCs by multiplying with x^(8n) mod P (crc32_combine), Adler sums by the closed-form block rule.
+// ---------------------------------------------------------------------------------------
+#define D4G_CSUM_CHUNK 512                       // bytes per thread
+#define D4G_CSUM_TILE (D4G_CSUM_CHUNK * 256)     // bytes per workgroup (128 KiB)
+struct D4GCsumRec { uint32_t crc; uint32_t s1; uint32_t s2; uint32_t pad; unsigned long long len; };
+struct D4GCsumOut { uint32_t crc32; uint32_t adler32; long long isize; };
+
+D4G_DEV uint32_t crc_multmodp(uint32_t a, uint32_t b) {  // zlib crc32.c multmodp (reflected CRC-32 polynomial)
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return p;
+}
+D4G_DEV uint32_t crc_x8nmodp(unsigned long long nbytes, const uint32_t* x2n) {  // x^(8*nbytes) mod P
+    uint32_t p = 1u << 31;
+    unsigned k = 3;
+    while (nbytes) {
+        if (nbytes & 1) p = crc_multmodp(x2n[k & 31], p);
+        nbytes >>= 1;
+        k++;
+    }
+    return p;
+}
+// ordered concatenation A ++ B of two checksum records (zlib crc32_combine / adler32_combine algebra)
+D4G_DEV void csum_concat(uint32_t& crc, uint32_t& s1, uint32_t& s2, unsigned long long& len, uint32_t crcB, uint32_t s1B, uint32_t s2B,
+                         unsigned long long lenB, const uint32_t* x2n) {
+    if (lenB == 0) return;
+    crc = len ? (crc_multmodp(crc_x8nmodp(lenB, x2n), crc) ^ crcB) : crcB;
+    s2 = (uint32_t)((s2 + (lenB % 65521u) * s1 + s2B) % 65521u);
+    s1 = (s1 + s1B) % 65521u;
+    len += lenB;
+}
+
+__global__ void __launch_bounds__(256) k_csum_tiles(const D4GStreamDesc* streams, const long long* tileBase, int nStreams,
+                                                    const uint8_t* U, const uint32_t* crcTab, D4GCsumRec* out) {
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t sx2n[32];
+    __shared__ uint32_t sCrc[256], sS1[256], sS2[256];
+    __shared__ unsigned long long sLen[256];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) T[i >> 8][i & 255] = crcTab[i];
+    if (threadIdx.x < 32) sx2n[threadIdx.x] = crcTab[1024 + threadIdx.x];
+    __syncthreads();
+    long long tile = blockIdx.x;
+    int lo = 0, hi = nStreams - 1;  // stream owning this tile (tileBase = exclusive prefix of tile counts)
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tileBase[mid] <= tile) lo = mid; else hi = mid - 1;
+    }
+    const D4GStreamDesc sd = streams[lo];
+    long long off = (tile - tileBase[lo]) * D4G_CSUM_TILE + (long long)threadIdx.x * D4G_CSUM_CHUNK;
+    long long len = sd.uLen - off;
+    if (len > D4G_CSUM_CHUNK) len = D4G_CSUM_CHUNK;
+    if (len < 0) len = 0;
+    const uint8_t* p = U + sd.uBase + off;  // 16-byte aligned: uBase is, offsets are multiples of 512
+    uint32_t crc = 0xffffffffu, s1 = 0, s2 = 0;
+    long long i = 0;
+    for (; i + 16 <= len; i += 16) {
+        uint4 v = *(const uint4*)(p + i);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t x = crc ^ w[j];
+            crc = T[3][x & 0xff] ^ T[2][(x >> 8) & 0xff] ^ T[1][(x >> 16) & 0xff] ^ T[0][x >> 24];
+            uint32_t b0 = w[j] & 0xff, b1 = (w[j] >> 8) & 0xff, b2 = (w[j] >> 16) & 0xff, b3 = w[j] >> 24;
+            uint32_t rem = (uint32_t)(len - i) - 4 * j;  // weight of b0 = bytes from it to the end of the chunk
+            s1 += b0 + b1 + b2 + b3;
+            s2 += rem * b0 + (rem - 1) * b1 + (rem - 2) * b2 + (rem - 3) * b3;
+        }
+    }
+    for (; i < len; i++) {
+        uint32_t b = p[i];
+        crc = T[0][(crc ^ b) & 0xff] ^ (crc >> 8);
+        s1 += b;
+        s2 += (uint32_t)(len - i) * b;
+    }
+    sCrc[threadIdx.x] = len ? crc ^ 0xffffffffu : 0u;
+    sS1[threadIdx.x] = s1 % 65521u;
+    sS2[threadIdx.x] = s2 % 65521u;
+    sLen[threadIdx.x] = (unsigned long long)len;
+    __syncthreads();
+    for (int step = 1; step < 256; step <<= 1) {
+        int t = threadIdx.x;
+        if ((t & (2 * step - 1)) == 0) csum_concat(sCrc[t], sS1[t], sS2[t], sLen[t], sCrc[t + step], sS1[t + step], sS2[t + step], sLen[t + step], sx2n);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        D4GCsumRec r;
+        r.crc = sCrc[0]; r.s1 = sS1[0]; r.s2 = sS2[0]; r.pad = 0; r.len = sLen[0];
+        out[tile] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_csum_combine(const D4GStreamDesc* streams, const long long* tileBase, const D4GCsumRec* recs,
+                                                      const uint32_t* x2n, D4GCsumOut* outs) {
+    __shared__ uint32_t sCrc[256], sS1[256], sS2[256];
+    __shared__ unsigned long long sLen[256];
+    __shared__ uint32_t sx2n[32];
+    const D4GStreamDesc sd = streams[blockIdx.x];
+    long long c0 = tileBase[blockIdx.x], c1 = tileBase[blockIdx.x + 1];
+    if (threadIdx.x < 32) sx2n[threadIdx.x] = x2n[threadIdx.x];
+    __syncthreads();
+    long long n = c1 - c0, per = (n + blockDim.x - 1) / blockDim.x;
+    long long a = c0 + (long long)threadIdx.x * per, e = a + per;
+    if (a > c1) a = c1;
+    if (e > c1) e = c1;
+    uint32_t crc = 0, s1 = 0, s2 = 0;
+    unsigned long long len = 0;
+    for (long long c = a; c < e; c++) {
+        D4GCsumRec k = recs[c];
+        csum_concat(crc, s1, s2, len, k.crc, k.s1, k.s2, k.len, sx2n);
+    }
+    sCrc[threadIdx.x] = crc; sS1[threadIdx.x] = s1; sS2[threadIdx.x] = s2; sLen[threadIdx.x] = len;
+    __syncthreads();
+    for (int step = 1; step < 256; step <<= 1) {
+        int t = threadIdx.x;
+        if ((t & (2 * step - 1)) == 0) csum_concat(sCrc[t], sS1[t], sS2[t], sLen[t], sCrc[t + step], sS1[t + step], sS2[t + step], sLen[t + step], sx2n);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // Adler-32 starts from a = 1, b = 0: a = 1 + S1, b = len*1 + S2 (mod 65521)
+        unsigned long long L = sLen[0];
+        uint32_t A = (1u + sS1[0]) % 65521u;
+        uint32_t B = (uint32_t)((L % 65521u + sS2[0]) % 65521u);
+        D4GCsumOut o;
+        o.crc32 = L ? sCrc[0] : 0u;
+        o.adler32 = (B << 16) | A;
+        o.isize = (long long)sd.uLen;
+        outs[blockIdx.x] = o;
+    }
+}

@@ -122,6 +122,38 @@ int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, siz
     }
 }
 
+int d4g_batch_parse(d4g_batch* b) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    if (!b) return fail(D4G_ERR_ARG, "null batch");
+    try {
+        if (b->impl.ran) return fail(D4G_ERR_ARG, "batch already ran");
+        b->impl.ran = true;
+        engine().init();
+        b->impl.parse_probe();
+        b->impl.build_blocks(false, false);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler32, int64_t* isize) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
+    if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
+    try {
+        b->impl.checksums();
+        const D4GCsumOut& o = b->impl.csums[i];
+        if (crc32) *crc32 = o.crc32;
+        if (adler32) *adler32 = o.adler32;
+        if (isize) *isize = o.isize;
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
 int d4g_batch_stats(d4g_batch* b, d4g_stats* st) {
     if (!b || !st) return fail(D4G_ERR_ARG, "null argument");
     *st = b->impl.stats;

@@ -45,6 +45,7 @@ typedef struct d4g_stats {
     int64_t state_launches;
     int64_t state_tokens_per_round, state_bytes_per_round; /* summed over k_exec_state_ops launches: tokens / decoded bytes of the blocks each launch covers */
     int64_t search_lanes;             /* block groups whose level sequences run concurrently (stream lanes) */
+    double ms_checksum_kernels;       /* device time of the CRC-32 / Adler-32 kernels (d4g_batch_checksums) */
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.
@@ -67,6 +68,12 @@ int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* sa
 int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap);
 /* copy stream i's decoded bytes (DeflateStream.getUncompressedData, :159-169) */
 int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, size_t* len);
+/* Trailer values of stream i computed on the device from its decoded bytes: CRC-32 and ISIZE as
+ * K/GZFile.java:129-145 recomputes them (java.util.zip.CRC32), Adler-32 as K/ZLibFile.java:41-51 does.
+ * Valid after d4g_batch_run (or d4g_batch_parse). */
+int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler32, int64_t* isize);
+/* parse + decode only (DeflateStream.parse for every stream); makes copy_decoded / checksums available */
+int d4g_batch_parse(d4g_batch* b);
 int d4g_batch_stats(d4g_batch* b, d4g_stats* st);
 void d4g_batch_destroy(d4g_batch* b);
 
