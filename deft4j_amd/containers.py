@@ -109,8 +109,170 @@ class ZLibFile:
         return bytes([self.cmf, self.flg]) + deflate + struct.pack(">I", adler32 & 0xffffffff)
 
 
+class PNGFile:
+    """K/PNGFile.java: chunk walk (:162-215), stream collection state machine (:413-544), re-chunking on write
+    (syncStreams :262-369).  One zlib stream for the concatenated IDAT chunks, one per APNG frame (fdAT chunks
+    between fcTLs), one per zTXt / iTXt / iCCP chunk."""
+    file_type = "PNG"
+    SIG = b"\x89PNG\r\n\x1a\n"
+
+    @staticmethod
+    def _zlib_offset(ty, d):   # PNGChunk.getZLibCompressedNonIdat — :84-113 (None: not deflate-compressed)
+        off = d.index(b"\0") + 2
+        if ty == b"iTXt":
+            if d[off - 1] != 1:
+                return None
+            off += 1
+        if d[off - 1] != 0:
+            return None
+        if ty == b"iTXt":
+            off = d.index(b"\0", off) + 1
+            off = d.index(b"\0", off) + 1
+        return off
+
+    def read(self, data):
+        import zlib as _z
+        d = bytes(data)
+        if d[:8] != self.SIG:
+            return False
+        self.chunks = []          # [type, data]
+        self.streams = []         # (kind, name, ZLibFile, chunk index for non-IDAT)
+        p = 8
+        reading_idat = reading_fdat = seen_actl = seen_idat = seen_iend = False
+        seq = 0
+        acc = bytearray()
+        nfd = 0
+
+        def flush():
+            nonlocal reading_idat, reading_fdat, seen_idat, nfd, acc
+            z = ZLibFile()
+            if not z.read(bytes(acc)):
+                return False
+            if reading_idat:
+                self.streams.append(("IDAT", "IDAT chunk", z, None))
+                seen_idat = True
+                reading_idat = False
+            else:
+                nfd += 1
+                self.streams.append(("fdAT", "fdAT chunk %d" % nfd, z, None))
+                reading_fdat = False
+            acc = bytearray()
+            return True
+
+        while True:
+            if p + 12 > len(d):
+                return False
+            ln = struct.unpack(">I", d[p:p + 4])[0]
+            ty = d[p + 4:p + 8]
+            cd = d[p + 8:p + 8 + ln]
+            crc = struct.unpack(">I", d[p + 8 + ln:p + 12 + ln])[0]
+            p += 12 + ln
+            if _z.crc32(ty + cd) != crc:          # PNGChunk.read returns calcCrc == CRC32
+                return False
+            if seen_iend:
+                return False
+            if ty in (b"fcTL", b"fdAT"):
+                s = struct.unpack(">I", cd[:4])[0]
+                if (seen_idat and not seen_actl) or s != seq:
+                    return False
+                seq += 1
+            if (reading_idat and ty != b"IDAT") or (reading_fdat and ty in (b"fcTL", b"IEND")):
+                if not flush():
+                    return False
+            self.chunks.append([ty, cd])
+            if ty == b"IEND":
+                seen_iend = True
+                break
+            if ty == b"acTL":
+                if seen_idat or seen_actl:
+                    return False
+                seen_actl = True
+                continue
+            if ty == b"fdAT":
+                if not seen_idat or reading_idat:
+                    return False
+                reading_fdat = True
+            elif ty == b"IDAT":
+                if seen_idat or reading_fdat:
+                    return False
+                reading_idat = True
+            if len(cd) > 0:
+                if reading_idat:
+                    acc += cd
+                elif reading_fdat and ty == b"fdAT":
+                    acc += cd[4:]
+                elif ty in (b"zTXt", b"iTXt", b"iCCP"):
+                    off = self._zlib_offset(ty, cd)
+                    if off is not None:
+                        z = ZLibFile()
+                        if z.read(cd[off:]):
+                            self.streams.append((ty.decode(), ty.decode() + " chunk", z, len(self.chunks) - 1))
+        if not (seen_idat and not reading_idat and not reading_fdat and (nfd == 0 or seen_actl)):
+            return False
+        # deft4j's stream order: IDAT, fdAT frames, then the other chunks (K/PNGFile.java:377-389)
+        self.streams.sort(key=lambda s: {"IDAT": 0, "fdAT": 1}.get(s[0], 2))
+        return True
+
+    def stream_payloads(self):
+        return [(name, z.payload) for _, name, z, _ in self.streams]
+
+    def write(self, zlib_outputs):
+        """zlib_outputs[i] = re-serialised zlib bytes of stream i (same order as stream_payloads)."""
+        import zlib as _z
+        chunks = [list(c) for c in self.chunks]
+        outs = {i: zlib_outputs[i] for i in range(len(self.streams))}
+        idat_i = [i for i, s in enumerate(self.streams) if s[0] == "IDAT"][0]
+        fd_is = [i for i, s in enumerate(self.streams) if s[0] == "fdAT"]
+        # non-IDAT chunks first (indices refer to the original chunk list)
+        for i, (kind, _, _, ci) in enumerate(self.streams):
+            if ci is not None:
+                ty, cd = chunks[ci]
+                off = self._zlib_offset(ty, cd)
+                chunks[ci][1] = cd[:off] + outs[i]
+        # IDAT: one chunk at the position of the first
+        first = next(k for k, c in enumerate(chunks) if c[0] == b"IDAT")
+        chunks = [c for c in chunks if c[0] != b"IDAT"]
+        chunks.insert(first, [b"IDAT", outs[idat_i]])
+        # fdAT frames: the first fdAT of each frame is replaced, the frame's other fdAT chunks are dropped
+        if fd_is:
+            res = []
+            k = 0
+            it = iter(fd_is)
+            cur = next(it, None)
+            state = "seek"
+            for c in chunks:
+                if cur is None:
+                    res.append(c)
+                    continue
+                if state == "seek":
+                    if c[0] == b"fdAT":
+                        res.append([b"fdAT", b"\0\0\0\0" + outs[cur]])
+                        state = "drop"
+                    else:
+                        res.append(c)
+                else:
+                    if c[0] == b"fdAT":
+                        continue
+                    res.append(c)
+                    if c[0] == b"fcTL":
+                        cur = next(it, None)
+                        state = "seek"
+            chunks = res
+            seq = 0
+            for c in chunks:
+                if c[0] in (b"fcTL", b"fdAT"):
+                    c[1] = struct.pack(">I", seq) + c[1][4:]
+                    seq += 1
+        out = bytearray(self.SIG)
+        for ty, cd in chunks:
+            out += struct.pack(">I", len(cd)) + ty + cd + struct.pack(">I", _z.crc32(ty + cd) & 0xffffffff)
+        return bytes(out)
+
+
 def detect(data):
-    """K/ContainerUtil.java:64-86 by magic bytes (gzip, zlib); anything else must be given explicitly."""
+    """K/ContainerUtil.java:64-86 by magic bytes (PNG, gzip, zlib); anything else must be given explicitly."""
+    if bytes(data[:8]) == PNGFile.SIG:
+        return PNGFile()
     d = bytes(data[:2])
     if d == b"\x1f\x8b":
         return GZFile()
@@ -122,7 +284,7 @@ def detect(data):
 def optimise_files(files, merge_blocks=True, formats=None, lib=None):
     """files: list of bytes.  formats: optional list of container instances / None (auto-detect) / "raw".
     Returns [(output bytes or None when unreadable, transcript lines)] — the lines M/CMDUtil.java:64-74 and
-    K/DeflateFilesContainer.java:31-40 print."""
+    K/DeflateFilesContainer.java:31-40 print.  Every deflate stream of every file goes to the GPU in one batch."""
     conts = []
     for i, f in enumerate(files):
         c = formats[i] if formats and formats[i] is not None else None
@@ -132,22 +294,45 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
             c = detect(f)
         ok = c is not None and c.read(f)
         conts.append(c if ok else None)
-    idx = [i for i, c in enumerate(conts) if c is not None]
-    batch = Batch([conts[i].payload for i in idx], lib=lib).run(merge_blocks) if idx else None
-    results = [(None, ["Failed to read file"]) for _ in files]
-    for k, i in enumerate(idx):
-        c = conts[i]
-        r = batch.result(k)
-        if r["status"] < 0:
+    payloads, owner = [], []
+    for i, c in enumerate(conts):
+        if c is None:
             continue
+        sp = c.stream_payloads() if isinstance(c, PNGFile) else [(c.name, c.payload)]
+        for name, pl in sp:
+            payloads.append(pl)
+            owner.append((i, name))
+    batch = Batch(payloads, lib=lib).run(merge_blocks) if payloads else None
+    results = [(None, ["Failed to read file"]) for _ in files]
+    k = 0
+    for i, c in enumerate(conts):
+        if c is None:
+            continue
+        n = len(c.stream_payloads()) if isinstance(c, PNGFile) else 1
         lines = ["File type recognised as " + c.file_type]
-        saved = r["saved_bits"]
-        if saved > 0:
-            lines.append("%d bits saved in stream 0 (%s)" % (saved, c.name))
-            lines.append("Total bits saved %d" % saved)
-            lines.append("Saved %d bits with optimisation" % saved)
-        crc, adler, isize = batch.checksums(k)
-        results[i] = (c.write(batch.output(k), crc, adler, isize), lines)
+        total = 0
+        ok = True
+        pieces = []
+        for j in range(n):
+            r = batch.result(k + j)
+            if r["status"] < 0:
+                ok = False
+                break
+            saved = r["saved_bits"]
+            if saved > 0:
+                lines.append("%d bits saved in stream %d (%s)" % (saved, j, owner[k + j][1]))
+            total += saved
+            pieces.append((batch.output(k + j), batch.checksums(k + j)))
+        if ok:
+            if total > 0:
+                lines.append("Total bits saved %d" % total)
+                lines.append("Saved %d bits with optimisation" % total)
+            if isinstance(c, PNGFile):
+                zl = [c.streams[j][2].write(pieces[j][0], *pieces[j][1]) for j in range(n)]
+                results[i] = (c.write(zl), lines)
+            else:
+                results[i] = (c.write(pieces[0][0], *pieces[0][1]), lines)
+        k += n
     if batch is not None:
         batch.close()
     return results

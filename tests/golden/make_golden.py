@@ -129,11 +129,9 @@ def main():
     z = open(REF + "deflate-fixed.txt.zz", "rb").read()
     open(os.path.join(HERE, "deflate-fixed-zz.parse.deflate"), "wb").write(z[2:-4])
     manifest["parse_only"].append({"stem": "deflate-fixed-zz", "source": "deflate-fixed.txt.zz", "in_len": len(z) - 6})
-    # whole container files (gzip) with their transcripts, for the container-level tests
+    # whole container files (gzip, PNG) with their transcripts, for the container-level tests
     manifest["files"] = []
     for inp, outp, merge in CASES:
-        if not inp.endswith(".gz"):
-            continue
         stem = inp.replace("/", "_")
         open(os.path.join(HERE, stem + ".file.in"), "wb").write(open(REF + inp, "rb").read())
         open(os.path.join(HERE, stem + ".file.out"), "wb").write(open(REF + outp, "rb").read())

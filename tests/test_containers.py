@@ -1,6 +1,7 @@
-"""Container level: whole gzip files through deft4j_amd.containers must equal the reference's
-golden output FILES byte for byte (header kept, deflate re-serialised, CRC-32/ISIZE recomputed on the device)
-and print the reference's transcript lines.  CPU tests run the kernels in the emulator; the GPU test uses
+"""Container level: whole gzip and PNG/APNG files through deft4j_amd.containers must equal the
+reference's golden output FILES byte for byte (gzip: header kept, deflate re-serialised, CRC-32/ISIZE recomputed on
+the device; PNG: IDAT / fdAT / zTXt / iTXt streams re-chunked as K/PNGFile.java does, Adler-32 from the device)
+and print the reference's transcript lines — this is runTestOpt.sh:3-11 end to end.  CPU tests run the kernels in the emulator; the GPU test uses
 the real library."""
 import json
 import os
@@ -55,7 +56,7 @@ def sim():
 
 
 def test_small_gzip_files_in_the_emulator(sim):
-    check_files(sim, [f for f in FILES if "asyoulik" not in f["stem"]])
+    check_files(sim, [f for f in FILES if f["stem"] in ("deflate-store-2.txt.gz", "lz-twice-twice.txt.gz", "text.png")])
     check_zlib_and_raw(sim)
 
 
@@ -69,7 +70,7 @@ def test_checksum_kernels_in_the_emulator(sim):
 
 
 @pytest.mark.gpu
-def test_all_gzip_files_on_the_gpu():
+def test_all_fixture_files_on_the_gpu():
     import deft4j_amd as D
     D.init(0)
     check_files(None, FILES)
