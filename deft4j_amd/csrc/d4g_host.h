@@ -38,6 +38,18 @@ static inline int state_block() {
     return v;
 }
 
+static inline int wide_block() {
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("D4G_WIDE_BLOCK");  // threads per workgroup for token-pass-only ops; 0 = same launch as the others
+        v = t ? atoi(t) : 0;
+        if (v != 0 && v != 256 && v != 512 && v != 1024) v = 0;
+    }
+#ifdef D4G_HOSTSIM
+    return 0;
+#endif
+    return v;
+}
 static inline int lanes() {
     static int v = 0;
     if (!v) {
@@ -92,7 +104,7 @@ struct Program {
     int32_t* dLists = nullptr;
     int32_t *dStateFlat = nullptr, *dHdrFlat = nullptr;  // level-ordered op ids for the persistent executor
     int nStateFlat = 0, nHdrFlat = 0;
-    std::vector<std::pair<size_t, int>> stateOff, hdrOff;
+    std::vector<std::pair<size_t, int>> stateOff, hdrOff, wideOff;  // per level: (offset into dLists, count)
     int nRequested = 0;  // ops the plain unrolling would have emitted (for the record)
 
     // ---- symbolic identity of a state, used to emit every distinct computation once ----
@@ -294,8 +306,14 @@ struct Program {
         rt_h2d(dOps, ops.data(), ops.size() * sizeof(D4GOp));
         std::vector<int32_t> lists;
         for (int l = 0; l < nLevels; l++) {
-            stateOff.push_back({lists.size(), (int)stateLevels[l].size()});
-            lists.insert(lists.end(), stateLevels[l].begin(), stateLevels[l].end());
+            // token-pass-only ops (no single-lane section) go to the wide-workgroup launch
+            std::vector<int> narrow, wide;
+            for (int id : stateLevels[l])
+                (wide_block() > 0 && (ops[id].kind == OP_OPT || ops[id].kind == OP_LEAST) ? wide : narrow).push_back(id);
+            stateOff.push_back({lists.size(), (int)narrow.size()});
+            lists.insert(lists.end(), narrow.begin(), narrow.end());
+            wideOff.push_back({lists.size(), (int)wide.size()});
+            lists.insert(lists.end(), wide.begin(), wide.end());
             hdrOff.push_back({lists.size(), (int)hdrLevels[l].size()});
             lists.insert(lists.end(), hdrLevels[l].begin(), hdrLevels[l].end());
         }
@@ -869,6 +887,11 @@ struct Batch {
                         stats.state_launches++;
                         stats.state_tokens_per_round += tokSum;
                         stats.state_bytes_per_round += uSum;
+                    }
+                    if (P.wideOff[l].second) {
+                        i64 grid = 8 * groups * P.wideOff[l].second;
+                        RT_LAUNCH(k_exec_state_ops_wide, grid, wide_block(), c, P.dLists + P.wideOff[l].first, P.wideOff[l].second);
+                        stats.kernel_launches++;
                     }
                     keep.emplace_back(new RtEvent());
                     keep.back()->record();

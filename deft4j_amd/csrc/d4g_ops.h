@@ -782,6 +782,15 @@ __global__ void __launch_bounds__(256) k_exec_state_ops(D4GCtx c, const int32_t*
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
+// Same body for the token-pass-only ops (optimise / least-expensive pruning): they have no single-lane
+// section, so they run with wide workgroups (up to 16 waves sweep the block's tokens together).
+__global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+    __shared__ D4GLds L;
+    int bs, orel;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
+}
+
 __global__ void __launch_bounds__(256) k_persist_state_ops(D4GCtx c, D4GQueue q) {
     __shared__ D4GLds L;
     __shared__ int sTask[3], sOk;
