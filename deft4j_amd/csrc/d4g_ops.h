@@ -111,15 +111,17 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
     __syncthreads();
     const uint2* tk = c.tok + b.tokStart;
     const uint8_t* Ub = c.U + b.uBase;
-    for (long long w0 = (long long)wave * K; w0 < b.maskWords; w0 += (long long)nw * K) {
+    const int nWords = (int)b.maskWords, nTok = (int)b.tokCount;  // a block's token count fits 31 bits
+    int savedLane = 0;
+    for (int w0 = wave * K; w0 < nWords; w0 += nw * K) {
         uint2 tokv[K];
         uint64_t mwv[K];
         // stage A: K token vectors and mask words in flight together
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            long long w = w0 + j, t = w * 64 + lane;
-            tokv[j] = (w < b.maskWords && t < b.tokCount) ? tk[t] : make_uint2(0u, 0u);
-            mwv[j] = w < b.maskWords ? ld_sc1(maskIn + w) : 0;
+            int w = w0 + j, t = w * 64 + lane;
+            tokv[j] = (w < nWords && t < nTok) ? tk[t] : make_uint2(0u, 0u);
+            mwv[j] = w < nWords ? ld_sc1(maskIn + w) : 0;
         }
         int bit[K], len[K], cost[K], total[K], cnt[K], have[K], lsym[K], dsym[K];
         bool undec[K], ok[K];
@@ -174,16 +176,16 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
         for (int j = 0; j < K; j++) {
             if (ok[j]) {
                 bit[j] = 1;
-                saved += cost[j] - total[j];
+                savedLane += cost[j] - total[j];
                 atomicSub(&S->hist[lsym[j]], 1u);
                 atomicSub(&S->hist[D4G_NLIT + dsym[j]], 1u);
                 for_bytes(Ub + tokv[j].y, len[j], [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
             }
             uint64_t nm = __ballot(bit[j]);
-            if (lane == 0 && w0 + j < b.maskWords) st_sc1(maskOut + w0 + j, nm);
+            if (lane == 0 && w0 + j < nWords) st_sc1(maskOut + w0 + j, nm);
         }
     }
-    saved = wg_sum_i64(saved, L->red);
+    saved = wg_sum_i64((long long)savedLane, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
     __syncthreads();
 }
