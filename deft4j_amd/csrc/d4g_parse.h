@@ -73,27 +73,31 @@ struct D4GParseLds {
 
 // Bit reader owned by lane 0 (B/io/BitInputStream.java:59-82: LSB-first).
 struct D4GBitReader {
-    long long inBase;      // absolute byte index of inbuf[0]
+    long long inBase;      // absolute byte index of inbuf[0] (multiple of 16)
     long long nbits;       // total bits of the stream
-    long long pos;         // bits consumed
+    // chunk-relative 32-bit state: the decode loop does no 64-bit position arithmetic
+    int rel;               // offset in inbuf of the next byte to load into buf
+    int posRel;            // bits consumed, relative to bit 8*inBase
+    int limitRel;          // stream end, relative to bit 8*inBase (clamped)
     uint64_t buf;
     int cnt;
-    long long nextByte;    // absolute index of the next byte to load into buf
+    __device__ long long pos() const { return inBase * 8 + posRel; }
     __device__ void reset_to(const uint8_t* inbuf, long long bitpos) {
-        pos = bitpos;
+        long long lim = nbits - inBase * 8;
+        limitRel = lim > 0x3fffffff ? 0x3fffffff : (int)lim;
+        posRel = (int)(bitpos - inBase * 8);
+        rel = posRel >> 3;
         buf = 0;
         cnt = 0;
-        nextByte = bitpos >> 3;
         // byte loads up to the next 4-byte boundary of the staged chunk, then aligned words
-        while ((nextByte - inBase) & 3) {
-            long long o = nextByte - inBase;
-            uint64_t v = (o >= 0 && o < D4G_INCH + 16) ? inbuf[o] : 0;
+        while (rel & 3) {
+            uint64_t v = (rel >= 0 && rel < D4G_INCH + 16) ? inbuf[rel] : 0;
             buf |= v << cnt;
             cnt += 8;
-            nextByte++;
+            rel++;
         }
         fill(inbuf);
-        int sh = (int)(bitpos & 7);
+        int sh = posRel & 7;
         buf >>= sh;
         cnt -= sh;
         fill(inbuf);
@@ -101,16 +105,16 @@ struct D4GBitReader {
     // Guarantees at least 33 valid bits (enough for one code + its extra bits).
     __device__ void fill(const uint8_t* inbuf) {
         while (cnt <= 32) {
-            long long o = nextByte - inBase;
-            uint64_t v = (o >= 0 && o + 4 <= D4G_INCH + 16) ? *(const uint32_t*)(inbuf + o) : 0;
+            uint64_t v = (rel >= 0 && rel + 4 <= D4G_INCH + 16) ? *(const uint32_t*)(inbuf + rel) : 0;
             buf |= v << cnt;
             cnt += 32;
-            nextByte += 4;
+            rel += 4;
         }
     }
-    __device__ bool have(int n) const { return pos + n <= nbits; }
-    __device__ void skip(int n) { buf >>= n; cnt -= n; pos += n; }
-    __device__ bool near_end() const { return nextByte + 1024 > inBase + D4G_INCH; }
+    __device__ int avail() const { return limitRel - posRel; }
+    __device__ bool have(int n) const { return posRel + n <= limitRel; }
+    __device__ void skip(int n) { buf >>= n; cnt -= n; posRel += n; }
+    __device__ bool near_end() const { return rel + 1024 > D4G_INCH; }
 };
 
 // Huffman.buildCodes (B/huffman/Huffman.java:35-64) + decoder tables.  Lane 0 prepares the
@@ -163,7 +167,7 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
 // Decode one symbol from `bits` (lane 0), `avail` = bits left in the stream.
 // Returns sym | len << 16, or -1 on failure.  (Packed return instead of an out-pointer: a generic
 // pointer to a private variable next to LDS table reads trips a gfx950 backend assertion in ROCm 7.2.)
-__device__ __forceinline__ int d4g_decode_sym_packed(const D4GDecTab* T, uint64_t bits, long long avail) {
+__device__ __forceinline__ int d4g_decode_sym_packed(const D4GDecTab* T, uint64_t bits, int avail) {
     unsigned e = T->lut[bits & ((1u << D4G_LUT_BITS) - 1)];
     if (e != 0xffff) {
         int l = e >> 9;
@@ -257,7 +261,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     D4GBitReader br;
     br.inBase = 0;
     br.nbits = sd.len * 8;
-    br.pos = 0; br.buf = 0; br.cnt = 0; br.nextByte = 0;
+    br.rel = 0; br.posRel = 0; br.limitRel = 0; br.buf = 0; br.cnt = 0;
     D4GState* S = &L.st;
     auto stage = [&](long long bitpos) {
         long long base = (bitpos >> 3) & ~15LL;
@@ -286,7 +290,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         // DeflateBlockUncompressed.parse — B/deflate/DeflateBlockUncompressed.java:23-36
         long long r = 0, p = 0;
         if (lane == 0) {
-            p = (br.pos + 7) & ~7LL;
+            p = (br.pos() + 7) & ~7LL;
             if (p + 32 > br.nbits) r = -1;
             else {
                 br.reset_to(L.inbuf, p);
@@ -356,7 +360,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
             while (i < combined && r == 0) {
                 br.fill(L.inbuf);
                 int cl = 0, sym;
-                D4G_DECODE(&L.cl, br.buf, br.nbits - br.pos, sym, cl);
+                D4G_DECODE(&L.cl, br.buf, br.avail(), sym, cl);
                 if (sym < 0 || sym > 18) { r = -1; break; }
                 br.skip(cl);
                 S->hdrBits += cl;
@@ -400,16 +404,21 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         if (!good) return;
     }
     // ---- decodeStream — DeflateBlockHuffman.java:778-890: lane 0 decodes, the wave refills the input chunk ----
-    long long litlenBits = 0, nTok = 0, nU = 0, needHist = 0;
+    // 32-bit counters inside the loop: a block's tokens, bytes and bits fit comfortably
+    unsigned litlenBits = 0, nTok = 0, nU = 0;
+    int needHist = 0;
+    uint2* tokOut = EMIT ? out.tok + em->tokStart : nullptr;
+    const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
     int done = 0;  // 1 EOB, -1 failure
     while (true) {
         long long code = 0;
         if (lane == 0) {
+            const bool chunkCoversEnd = br.inBase + D4G_INCH >= sd.len + 16;
             while (true) {
-                if (br.near_end() && br.inBase + D4G_INCH < sd.len + 16) { code = 2; break; }  // refill needed
+                if (br.near_end() && !chunkCoversEnd) { code = 2; break; }  // refill needed
                 br.fill(L.inbuf);
                 uint64_t bits = br.buf;
-                long long avail = br.nbits - br.pos;
+                int avail = br.avail();
                 int cl = 0, val = 0, dist = 0, edge = 0, used = 0;
                 int sym;
                 D4G_DECODE(&L.lit, bits, avail, sym, cl);
@@ -425,7 +434,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                     br.skip(used);
                     br.fill(L.inbuf);           // second refill: distance code + extra bits (<= 28 bits)
                     bits = br.buf;
-                    avail = br.nbits - br.pos;
+                    avail = br.avail();
                     int dcl = 0, ds;
                     D4G_DECODE(&L.dist, bits, avail, ds, dcl);
                     if (ds < 0 || ds > 29) { code = -1; break; }
@@ -434,23 +443,20 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                     dist = d4g_dsym_base(ds) + (int)((bits >> dcl) & ((1u << deb) - 1));
                     br.skip(dcl + deb);
                     used += dcl + deb;
-                    if (dist - nU > needHist) needHist = dist - nU;
+                    if (nU < 32768u && dist - (int)nU > needHist) needHist = dist - (int)nU;  // only the block's first 32 KiB can reach back past its start
                     if (EMIT) { S->hist[sym]++; S->hist[D4G_NLIT + ds]++; }
                     val = len;
                 }
-                litlenBits += used;
-                if (EMIT) {
-                    out.tok[em->tokStart + nTok] = make_uint2((uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16),
-                                                              (uint32_t)(em->uStart + nU));
-                }
+                litlenBits += (unsigned)used;
+                if (EMIT) tokOut[nTok] = make_uint2((uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16), uStart32 + nU);
                 nTok++;
                 if (sym == 256) { code = 1; break; }
-                nU += dist ? val : 1;
+                nU += dist ? (unsigned)val : 1u;
             }
         }
         code = __shfl(code, 0);
         if (code == 2) {
-            long long bitpos = __shfl((long long)br.pos, 0);
+            long long bitpos = __shfl(br.pos(), 0);
             stage(bitpos);
             continue;
         }
@@ -459,18 +465,18 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     }
     if (done < 0) return;
     if (lane == 0) {
-        S->litlenBits = litlenBits;
-        S->sizeBits = S->hdrBits + litlenBits;
+        S->litlenBits = (long long)litlenBits;
+        S->sizeBits = S->hdrBits + (long long)litlenBits;
         S->valid = 1;
         S->maskSlot = 0;
     }
     __syncthreads();
     po.status = 0;
-    po.endBit = __shfl((long long)br.pos, 0);
-    po.nTok = __shfl(nTok, 0);
-    po.uLen = __shfl(nU, 0);
+    po.endBit = __shfl(br.pos(), 0);
+    po.nTok = (long long)__shfl(nTok, 0);
+    po.uLen = (long long)__shfl(nU, 0);
     po.sizeBits = S->sizeBits;
-    po.needHist = __shfl(needHist, 0);
+    po.needHist = (long long)__shfl(needHist, 0);
     if (EMIT) {
         D4GState* g = out.states + em->stateIdx;
         for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
