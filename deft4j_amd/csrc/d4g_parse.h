@@ -42,7 +42,15 @@ struct D4GProbeOut {
     long long endBit;      // first bit after the block
     long long nTok, uLen, sizeBits;
     long long needHist;    // max over back-references of (distance - bytes produced so far in the block)
+    int32_t nCp;           // checkpoints recorded
+    int32_t pad;
 };
+// Probes leave up to 32 checkpoints per block (token boundaries with their bit position and running
+// token / byte counts) so that the emit pass can decode a block's segments in parallel.
+#define D4G_MAXCP 32
+struct D4GCheckpoint { long long bitPos; unsigned nTok; unsigned nU; };
+struct D4GCpSet { int32_t n; int32_t pad; D4GCheckpoint cp[D4G_MAXCP]; };
+
 struct D4GEmitIn {
     int32_t stream;
     int32_t type;
@@ -51,6 +59,19 @@ struct D4GEmitIn {
     long long uStart;      // stream-relative offset of the block's decoded bytes
     long long uLen;
     long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
+    long long sizeBits;    // from the probe
+    long long cpIndex;     // index of the block's checkpoint set (-1: none, the block is one segment)
+    int32_t nCp;
+    int32_t pad;
+};
+struct D4GEmitSeg { int32_t emit; int32_t seg; };  // segment `seg` (0..nCp) of emit job `emit`
+// how d4g_parse_block runs
+struct D4GSegCtl {
+    int mode;              // 0 whole block; 1 header only (write the block's state with an empty histogram); 2 one segment
+    long long startBit;    // mode 2, seg > 0: first bit of the segment (a token boundary)
+    unsigned startTok, startU;
+    long long endBit;      // mode 2: stop at this token boundary (-1: run to EOB)
+    D4GCpSet* cpOut;       // mode 0, probe: where to leave the checkpoints (may be null)
 };
 
 #define D4G_LUT_BITS 10
@@ -69,6 +90,7 @@ struct D4GParseLds {
     D4GState st;
     D4GDecTab lit, dist, cl;
     alignas(16) uint8_t inbuf[D4G_INCH + 16];
+    D4GCpSet cps;          // probe: checkpoints recorded for the block
 };
 
 // Bit reader owned by lane 0 (B/io/BitInputStream.java:59-82: LSB-first).
@@ -255,7 +277,7 @@ struct D4GParseOut {
 
 template <bool EMIT>
 __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long long bitPos, int strict, D4GProbeOut& po,
-                                const D4GEmitIn* em, const D4GParseOut& out) {
+                                const D4GEmitIn* em, const D4GParseOut& out, const D4GSegCtl& sc) {
     __shared__ D4GParseLds L;
     int lane = threadIdx.x & 63;
     D4GBitReader br;
@@ -263,6 +285,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     br.nbits = sd.len * 8;
     br.rel = 0; br.posRel = 0; br.limitRel = 0; br.buf = 0; br.cnt = 0;
     D4GState* S = &L.st;
+    int segEndRel = 0x7fffffff;  // segment end relative to the staged chunk (mode 2)
     auto stage = [&](long long bitpos) {
         long long base = (bitpos >> 3) & ~15LL;
         if (base > sd.len) base = sd.len & ~15LL;
@@ -271,7 +294,10 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         __syncthreads();
         br.inBase = base;
         if (lane == 0) br.reset_to(L.inbuf, bitpos);
+        long long e = sc.endBit - base * 8;
+        segEndRel = (sc.mode == 2 && sc.endBit >= 0) ? (e > 0x3fffffff ? 0x3fffffff : (int)e) : 0x7fffffff;
     };
+    po.nCp = 0; po.pad = 0;
     po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
     stage(bitPos);
     long long pk = 0;
@@ -394,6 +420,21 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         r = __shfl(r, 0);
         if (r < 0) return;
     }
+    if (EMIT && sc.mode == 1) {
+        // header only: the block's state with an empty histogram (the segment waves add their counts)
+        if (lane == 0) {
+            if (btype == 1) { S->litLen[286] = 0; S->litLen[287] = 0; }
+            S->sizeBits = em->sizeBits;
+            S->litlenBits = em->sizeBits - S->hdrBits;
+            S->valid = 1;
+            S->maskSlot = 0;
+        }
+        __syncthreads();
+        D4GState* g = out.states + em->stateIdx;
+        for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
+        po.status = 0;
+        return;
+    }
     d4g_build_decoder(&L.lit, S->litLen, btype == 1 ? 288 : S->nLit);
     d4g_build_decoder(&L.dist, S->distLen, btype == 1 ? 30 : S->nDist);
     if (btype == 1 && lane == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
@@ -409,13 +450,39 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     int needHist = 0;
     uint2* tokOut = EMIT ? out.tok + em->tokStart : nullptr;
     const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
-    int done = 0;  // 1 EOB, -1 failure
+    if (EMIT && sc.mode == 2) {
+        if (sc.startBit >= 0) stage(sc.startBit);   // segment > 0 starts at a checkpoint; segment 0 right after the header
+        nTok = sc.startTok;
+        nU = sc.startU;
+    }
+    // probe: checkpoints every `cpSpacing` tokens; when the set is full every other one is dropped
+    unsigned cpSpacing = 1024, nextCp = 1024;
+    int nCp = 0;
+    const bool recordCp = !EMIT && sc.cpOut != nullptr;
+    int done = 0;  // 1 EOB, 3 segment end, -1 failure
     while (true) {
         long long code = 0;
         if (lane == 0) {
             const bool chunkCoversEnd = br.inBase + D4G_INCH >= sd.len + 16;
             while (true) {
                 if (br.near_end() && !chunkCoversEnd) { code = 2; break; }  // refill needed
+                if (EMIT && br.posRel >= segEndRel) { code = br.posRel == segEndRel ? 3 : -1; break; }
+                if (recordCp && nTok == nextCp) {
+                    nextCp += 1024;
+                    if ((nTok & (cpSpacing - 1)) == 0) {
+                        if (nCp == D4G_MAXCP) {  // keep the checkpoints at multiples of twice the spacing
+                            for (int i = 0; i < D4G_MAXCP / 2; i++) L.cps.cp[i] = L.cps.cp[2 * i + 1];
+                            nCp = D4G_MAXCP / 2;
+                            cpSpacing *= 2;
+                        }
+                        if ((nTok & (cpSpacing - 1)) == 0) {
+                            L.cps.cp[nCp].bitPos = br.pos();
+                            L.cps.cp[nCp].nTok = nTok;
+                            L.cps.cp[nCp].nU = nU;
+                            nCp++;
+                        }
+                    }
+                }
                 br.fill(L.inbuf);
                 uint64_t bits = br.buf;
                 int avail = br.avail();
@@ -464,6 +531,19 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         break;
     }
     if (done < 0) return;
+    if (EMIT && sc.mode == 2) {
+        // a segment adds its symbol counts to the block's histogram and reports where it stopped
+        __syncthreads();
+        uint32_t* gh = out.states[em->stateIdx].hist;
+        for (int i = lane; i < D4G_HIST; i += 64)
+            if (S->hist[i]) atomicAdd(&gh[i], S->hist[i]);
+        po.status = (done == 3 && sc.endBit < 0) ? -1 : 0;   // the last segment must end at the EOB
+        po.endBit = __shfl(br.pos(), 0);
+        po.nTok = (long long)__shfl(nTok, 0);
+        po.uLen = (long long)__shfl(nU, 0);
+        if (done == 1 && sc.endBit >= 0) po.status = -1;      // an inner segment must not see the EOB
+        return;
+    }
     if (lane == 0) {
         S->litlenBits = (long long)litlenBits;
         S->sizeBits = S->hdrBits + (long long)litlenBits;
@@ -471,6 +551,13 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         S->maskSlot = 0;
     }
     __syncthreads();
+    if (recordCp) {
+        int n = __shfl(nCp, 0);
+        po.nCp = n;
+        if (lane == 0) L.cps.n = n;
+        __syncthreads();
+        for (int i = lane; i < (int)(sizeof(D4GCpSet) / 4); i += 64) ((uint32_t*)sc.cpOut)[i] = ((uint32_t*)&L.cps)[i];
+    }
     po.status = 0;
     po.endBit = __shfl(br.pos(), 0);
     po.nTok = (long long)__shfl(nTok, 0);
@@ -483,20 +570,44 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     }
 }
 
-__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n) {
+__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
+                                                     D4GCpSet* cpPool) {
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
     D4GParseOut none = {nullptr, nullptr, nullptr};
-    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
+    D4GSegCtl sc = {0, -1, 0u, 0u, -1, cpPool ? cpPool + blockIdx.x : nullptr};
+    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none, sc);
     if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
 }
 
-__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
+// Emit, step 1: one wave per block re-reads the header and writes the block's initial state (stored blocks:
+// their bytes).  Step 2: one wave per segment decodes its tokens.
+__global__ void __launch_bounds__(64) k_emit_init(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
     const D4GEmitIn em = in[blockIdx.x];
     D4GProbeOut po;
-    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out);
-    if ((threadIdx.x & 63) == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
+    D4GSegCtl sc = {1, -1, 0u, 0u, -1, nullptr};
+    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, sc);
+    if ((threadIdx.x & 63) == 0 && (po.status != 0 || (em.type == D4G_STORED && po.uLen != em.uLen))) atomicAdd(errors, 1);
+}
+
+__global__ void __launch_bounds__(64) k_emit_segments(const D4GStreamDesc* streams, const D4GEmitIn* in, const D4GEmitSeg* segs,
+                                                      const D4GCpSet* cpPool, D4GParseOut out, int32_t* errors) {
+    const D4GEmitSeg sg = segs[blockIdx.x];
+    const D4GEmitIn em = in[sg.emit];
+    D4GSegCtl sc = {2, -1, 0u, 0u, -1, nullptr};
+    if (em.cpIndex >= 0) {
+        const D4GCpSet* cs = cpPool + em.cpIndex;
+        if (sg.seg > 0) { sc.startBit = cs->cp[sg.seg - 1].bitPos; sc.startTok = cs->cp[sg.seg - 1].nTok; sc.startU = cs->cp[sg.seg - 1].nU; }
+        if (sg.seg < em.nCp) sc.endBit = cs->cp[sg.seg].bitPos;
+    }
+    D4GProbeOut po;
+    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, sc);
+    if ((threadIdx.x & 63) == 0) {
+        bool bad = po.status != 0;
+        if (!bad && sc.endBit < 0 && po.uLen != em.uLen) bad = true;   // the last segment ends the block
+        if (bad) atomicAdd(errors, 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -61,3 +61,23 @@ def test_batch_of_synthetic_streams_matches_oracle(sim):
             if rc >= 0:
                 assert r["saved_bits"] == saved and b.output(i) == want, (i, merge)
         b.close()
+
+
+def test_long_blocks_decode_in_checkpoint_segments(sim):
+    """Blocks longer than 1024 tokens are emitted by one wave per checkpoint segment (and blocks beyond 32 Ki
+    tokens thin their checkpoint set): tokens, decoded bytes and the merged histogram must still be exact."""
+    D, L = sim
+    raw = synth.reptext(400000, 5)
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)  # memLevel 9: 32 Ki symbols per block
+    s9 = c.compress(raw) + c.flush()
+    rc, merged, _, _, _ = O.optimise(synth.deflate9(raw), True)  # one block of > 32 Ki tokens
+    assert rc == 0 and max(bi[1] for bi in O.block_info(merged)) > 32768
+    b = D.Batch([s9], lib=L).parse()
+    assert b.decoded(0) == raw
+    b.close()
+    rc, want, saved, _, _ = O.optimise(merged, False)
+    b = D.Batch([merged], lib=L).run(False)
+    r = b.result(0)
+    assert r["status"] == rc and r["saved_bits"] == saved and b.decoded(0) == raw
+    assert b.output(0) == (want if rc == 0 else merged)
+    b.close()
