@@ -53,6 +53,16 @@ __device__ const uint8_t D4G_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 1
 D4G_DEV int tok_val(uint32_t a) { return (int)(a & 0x1ffu); }
 D4G_DEV int tok_edge(uint32_t a) { return (int)((a >> 15) & 1u); }
 D4G_DEV int tok_dist(uint32_t a) { return (int)(a >> 16); }
+// bytes [sh/8, sh/8+4) of the little-endian pair {lo, hi}; sh in {0, 8, 16, 24} (v_alignbit_b32)
+D4G_DEV uint32_t d4g_alignbit(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+// back-reference record helpers (refs[r].x, see d4g_types.h)
+D4G_DEV uint32_t d4g_ref_pack(int len, int lsym, int dsym, int ebits) {
+    return (uint32_t)len | ((uint32_t)(lsym - 257) << 9) | ((uint32_t)dsym << 14) | ((uint32_t)ebits << 19);
+}
+D4G_DEV int ref_len(uint32_t a) { return (int)(a & 0x1ffu); }
+D4G_DEV int ref_lsym(uint32_t a) { return 257 + (int)((a >> 9) & 31u); }
+D4G_DEV int ref_dsym(uint32_t a) { return (int)((a >> 14) & 31u); }
+D4G_DEV int ref_ebits(uint32_t a) { return (int)((a >> 19) & 31u); }
 
 // ---------------------------------------------------------------------------------------
 // wave64 / workgroup reductions

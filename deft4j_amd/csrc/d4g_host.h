@@ -427,6 +427,7 @@ struct HBlock {
     int type = 0;        // current type (a Huffman block may have become STORED)
     int gpu = -1;        // device block index (Huffman blocks and merge arenas)
     i64 tokStart = 0, tokCount = 0, uStart = 0, uLen = 0;
+    i64 refStart = 0, refCount = 0;   // back-reference records of the block's tokens
     i64 size = 0;        // Huffman: sizeBits of the current state
     std::vector<D4GRoundResult> chain;  // phase-1 optimiseBlock rounds
     i64 size_at(i64 alignment) const {  // getSizeBits(alignment)
@@ -442,7 +443,7 @@ struct HStream {
     std::vector<HBlock> blocks;
     i64 consumed = 0, sizeBitsIn = 0, saved = 0;
     i64 inOff = 0, inLen = 0;
-    i64 tokBase = 0, uBase = 0, nTok = 0, nU = 0;
+    i64 tokBase = 0, uBase = 0, nTok = 0, nU = 0, refBase = 0, nRef = 0;
     i64 outWordBase = 0, outBits = 0;
     int arena[2] = {-1, -1};
     // mergeBlocks state machine
@@ -459,6 +460,8 @@ struct Batch {
     // device
     uint8_t* dIn = nullptr;
     uint2* dTok = nullptr;
+    uint2* dRefs = nullptr;       // back-reference records
+    uint32_t* dTokRef = nullptr;  // token -> record index
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -476,14 +479,14 @@ struct Batch {
     bool ran = false;
 
     ~Batch() {
-        rt_free(dIn); rt_free(dTok); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dCpPool); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -512,7 +515,7 @@ struct Batch {
     }
 
     // ---- parse: header scan -> block probes -> chain -> emit -> pointer jumping ----
-    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits; i64 cpIndex; int nCp; };
+    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits; i64 cpIndex; int nCp; i64 nRef; };
     struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; };
     std::vector<PStream> ps;
     D4GStreamDesc* dStreams = nullptr;
@@ -588,7 +591,7 @@ struct Batch {
         auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o, i64 cpIndex) {
             PStream& P = ps[i];
             if (o.status != 0 || o.needHist > upos[i]) { P.status = -1; done[i] = 1; return; }
-            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, o.nCp > 0 ? cpIndex : -1, o.nCp > 0 ? o.nCp : 0});
+            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, o.nCp > 0 ? cpIndex : -1, o.nCp > 0 ? o.nCp : 0, (i64)o.nRef});
             upos[i] += o.uLen;
             P.nTok += o.nTok;
             spos[i] += 3;  // DeflateStream.getSizeBits — :171-182
@@ -641,11 +644,12 @@ struct Batch {
         int masksAlloc = needSlots ? E.masksPerBlock : 1;
         hBlocks.clear();
         gpuType.clear();
-        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0;
+        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0;
         std::vector<D4GStreamDesc> sd(n);
         std::vector<D4GEmitIn> emits;
         std::vector<D4GTokRange> ranges;
-        auto add_block = [&](int stream, i64 tokStart, i64 tokCount, i64 uStart, i64 uLen, i64 maskWordsCap, int type) {
+        auto add_block = [&](int stream, i64 tokStart, i64 tokCount, i64 refStart, i64 refCount, i64 uStart, i64 uLen, i64 maskWordsCap,
+                             int type) {
             D4GBlock b;
             memset(&b, 0, sizeof(b));
             b.type = type;
@@ -657,7 +661,9 @@ struct Batch {
             b.uLen = uLen;
             b.stateIdx = (i64)hBlocks.size() * slotsAlloc;
             b.maskBase = maskWordsTotal;
-            b.maskWords = (tokCount + 63) / 64;
+            b.maskWords = (refCount + 63) / 64;
+            b.refStart = refStart;
+            b.refCount = refCount;
             maskWordsTotal += maskWordsCap * masksAlloc;
             hBlocks.push_back(b);
             gpuType.push_back(type);
@@ -672,6 +678,7 @@ struct Batch {
             s.nTok = P.nTok;
             s.nU = P.nU;
             s.tokBase = tokTot;
+            s.refBase = refTot;
             s.uBase = uTot;
             sd[si].data = dIn + s.inOff;
             sd[si].len = s.inLen;
@@ -681,7 +688,7 @@ struct Batch {
             uTot += (P.nU + 15) & ~15LL;
             if (P.status != 0) continue;
             int nHuff = 0;
-            i64 tpos = 0, upos = 0;
+            i64 tpos = 0, upos = 0, rpos = 0;
             for (const PBlock& pb : P.blocks) {
                 HBlock hb;
                 hb.type = pb.type;
@@ -689,6 +696,8 @@ struct Batch {
                 hb.tokCount = pb.nTok;
                 hb.uStart = upos;
                 hb.uLen = pb.uLen;
+                hb.refStart = s.refBase + rpos;
+                hb.refCount = pb.type == D4G_STORED ? 0 : pb.nRef;
                 hb.size = pb.sizeBits;
                 D4GEmitIn em;
                 memset(&em, 0, sizeof(em));
@@ -702,8 +711,10 @@ struct Batch {
                 em.sizeBits = pb.sizeBits;
                 em.cpIndex = pb.cpIndex;
                 em.nCp = pb.nCp;
+                em.refStart = hb.refStart;
                 if (pb.type != D4G_STORED) {
-                    hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.uStart, hb.uLen, (hb.tokCount + 63) / 64, pb.type);
+                    hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.refStart, hb.refCount, hb.uStart, hb.uLen, (hb.refCount + 63) / 64,
+                                       pb.type);
                     em.stateIdx = hBlocks[hb.gpu].stateIdx;
                     nHuff++;
                 }
@@ -712,17 +723,23 @@ struct Batch {
                 s.blocks.push_back(hb);
                 tpos += pb.nTok;
                 upos += pb.uLen;
+                rpos += hb.refCount;
                 stats.n_blocks++;
             }
+            s.nRef = rpos;
+            refTot += rpos;
             stats.n_tokens += P.nTok;
             stats.bytes_decoded += P.nU;
             if (merge && needSlots && nHuff >= 2) {
-                for (int a = 0; a < 2; a++) s.arena[a] = add_block((int)si, s.tokBase, 0, 0, 0, (P.nTok + 63) / 64 + 1, D4G_FIXED);
+                for (int a = 0; a < 2; a++) s.arena[a] = add_block((int)si, s.tokBase, 0, s.refBase, 0, 0, 0, (s.nRef + 63) / 64 + 1, D4G_FIXED);
             }
         }
         size_t nb = hBlocks.size();
         rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
+        if (refTot >= (1LL << 32)) throw std::runtime_error("batch holds 2^32 or more back-references: split it");
         dTok = (uint2*)rt_malloc((size_t)tokTot * 8 + 64);
+        dRefs = (uint2*)rt_malloc((size_t)refTot * 8 + 64);
+        dTokRef = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
         dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
         dSrc = (uint32_t*)rt_malloc((size_t)uTot * 4 + 64);
         if (nb) {
@@ -739,8 +756,7 @@ struct Batch {
             dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
             dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
             // mask 0 of every block starts empty (no back-reference expanded)
-            if (needSlots)
-                for (size_t b = 0; b < nb; b++) rt_memset(dMasks + hBlocks[b].maskBase, 0, (size_t)hBlocks[b].maskWords * 8);
+            if (needSlots) rt_memset(dMasks, 0, (size_t)maskWordsTotal * 8);   // one fill instead of one per block
         }
         RtEvent e0, e1;
         e0.record();
@@ -748,7 +764,7 @@ struct Batch {
             // 3. emit
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
-            D4GParseOut po = {dTok, dU, dStates};
+            D4GParseOut po = {dTok, dU, dStates, dRefs, dTokRef};
             RT_LAUNCH(k_emit_init, emits.size(), 64, dStreams, dEm, po, E.dErrors);
             stats.kernel_launches++;
             std::vector<D4GEmitSeg> segs;
@@ -1073,9 +1089,11 @@ struct Batch {
                         D4GBlock& d = hBlocks[ar];
                         d.tokStart = cur.tokStart;
                         d.tokCount = cur.tokCount + next.tokCount;
+                        d.refStart = cur.refStart;
+                        d.refCount = cur.refCount + next.refCount;
                         d.uStart = cur.uStart;
                         d.uLen = cur.uLen + next.uLen;
-                        d.maskWords = (d.tokCount + 63) / 64;
+                        d.maskWords = (d.refCount + 63) / 64;
                         d.type = D4G_FIXED;
                         req->stream = si;
                         req->arena = ar;
@@ -1104,6 +1122,8 @@ struct Batch {
         HBlock m;
         m.tokStart = cur.tokStart;
         m.tokCount = cur.tokCount + next.tokCount;
+        m.refStart = cur.refStart;
+        m.refCount = cur.refCount + next.refCount;
         m.uStart = cur.uStart;
         m.uLen = uLen;
         i64 ss = 0;

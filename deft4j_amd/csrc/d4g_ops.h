@@ -24,6 +24,8 @@ D4G_DEV int ld_state_i32(const int32_t* p) { return (int)ld_sc1((const uint32_t*
 
 struct D4GCtx {
     const uint2* tok;         // {token word, decoded-byte offset}
+    const uint2* refs;        // back-reference records {packed symbols/length, decoded-byte offset}
+    const uint32_t* tokRef;   // token -> back-reference record index
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -50,9 +52,15 @@ struct D4GLds {
     alignas(16) unsigned char treeDist[TreeMem<uint64_t, uint16_t, D4G_NDIST>::bytes(1)];
     alignas(16) unsigned char treeCl[TreeMem<uint32_t, uint8_t, 20>::bytes(1)];
     uint16_t clFreq[20];
+    uint16_t litCost[256];    // bits of each literal under the state's code; absent symbols cost D4G_NO_CODE
 };
 
 D4G_DEV uint64_t* mask_ptr(const D4GCtx& c, const D4GBlock& b, int slot) { return c.masks + b.maskBase + (long long)slot * b.maskWords; }
+// mask bit of the back-reference record `ref` (absolute index) of a block whose records start at refStart
+D4G_DEV bool d4g_ref_expanded(const uint64_t* mask, uint32_t ref, long long refStart) {
+    uint32_t r = ref - (uint32_t)refStart;
+    return (mask[r >> 6] >> (r & 63)) & 1;
+}
 D4G_DEV D4GState* state_ptr(const D4GCtx& c, int blockIdx_, int slot) { return c.states + ((long long)blockIdx_ * c.slotsPerBlock + slot); }
 
 D4G_DEV void wg_copy_words(uint32_t* dst, const uint32_t* src, int n) {
@@ -95,97 +103,127 @@ D4G_DEV void for_bytes(const uint8_t* p, int len, Fn fn) {
     }
 }
 #define D4G_LONG_TOKEN 32  // back-references longer than this are summed by the whole wave
+#define D4G_NO_CODE 0x4000 // literal cost of a byte whose symbol has no code: above any real sum (258 * 15)
+
+// litCost[v] for the state's current literal/length code (ends with a barrier)
+D4G_DEV void wg_fill_lit_cost(D4GLds* L) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        int l = L->st.litLen[i];
+        L->litCost[i] = (uint16_t)(l ? l : D4G_NO_CODE);
+    }
+    __syncthreads();
+}
+
+// Literal cost of a back-reference's decoded bytes, four bytes per step: the bytes are taken from the
+// block's decoded data with aligned words (Uw = the stream's region of U, 16-byte aligned and padded).
+struct D4GLitWalk {
+    uint32_t widx;   // next word to request
+    uint32_t cur, nxt;
+    int sh;          // bit offset of the first byte in `cur`
+    int rem;         // bytes left
+    int total;
+};
+D4G_DEV void lw_start(D4GLitWalk& w, const uint32_t* Uw, uint32_t off, int len) {
+    w.widx = off >> 2;
+    w.sh = (int)(off & 3u) * 8;
+    w.cur = Uw[w.widx];
+    w.nxt = Uw[w.widx + 1];
+    w.widx += 2;
+    w.rem = len;
+    w.total = 0;
+}
+D4G_DEV void lw_step(D4GLitWalk& w, const uint32_t* Uw, const uint16_t* lc) {
+    uint32_t x = d4g_alignbit(w.nxt, w.cur, w.sh);
+    w.cur = w.nxt;
+    w.nxt = Uw[w.widx++];
+    int l0 = lc[x & 255u], l1 = lc[(x >> 8) & 255u], l2 = lc[(x >> 16) & 255u], l3 = lc[x >> 24];
+    int n = w.rem;
+    w.total += l0 + (n > 1 ? l1 : 0) + (n > 2 ? l2 : 0) + (n > 3 ? l3 : 0);
+    w.rem = n - 4;
+}
 
 // ---------------------------------------------------------------------------------------
 // replaceBackrefsWithLiteralsIfSmaller — DeflateBlockHuffman.java:312-319 over :222-296.
-// One lane per token, 64 tokens per wave step; the new mask word is the wave ballot.
+// One lane per back-reference record, 64 per wave step; the new mask word is the wave ballot.
+// A back-reference is expanded when all its bytes have codes and their bits sum below its own
+// cost (`prune`: not above).  The sum is monotone, so the reference's byte-by-byte early exit is
+// the same as comparing the whole sum — lanes stop as soon as the bound is reached.
 // The histogram follows the token list (back-reference symbols out, literal bytes in).
 // ---------------------------------------------------------------------------------------
-#define D4G_TOK_ILP 4  // tokens per lane per step: four independent dependency chains hide LDS / L2 latency
+#define D4G_TOK_ILP 2  // records per lane per step: independent chains hide LDS / L2 latency
 __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
                                     bool prune) {
     D4GState* S = &L->st;
     const int K = D4G_TOK_ILP;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    long long saved = 0;
     __syncthreads();
-    const uint2* tk = c.tok + b.tokStart;
+    wg_fill_lit_cost(L);
+    const uint16_t* lc = L->litCost;
+    const uint2* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
-    const int nWords = (int)b.maskWords, nTok = (int)b.tokCount;  // a block's token count fits 31 bits
+    const uint32_t* Uw = (const uint32_t*)Ub;
+    const int nWords = (int)b.maskWords, nRef = (int)b.refCount;  // a block's counts fit 31 bits
     int savedLane = 0;
     for (int w0 = wave * K; w0 < nWords; w0 += nw * K) {
-        uint2 tokv[K];
+        uint2 rv[K];
         uint64_t mwv[K];
-        // stage A: K token vectors and mask words in flight together
+        // stage A: K records and mask words in flight together
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            int w = w0 + j, t = w * 64 + lane;
-            tokv[j] = (w < nWords && t < nTok) ? tk[t] : make_uint2(0u, 0u);
+            int w = w0 + j, r = w * 64 + lane;
+            rv[j] = (w < nWords && r < nRef) ? rf[r] : make_uint2(0u, 0u);
             mwv[j] = w < nWords ? ld_sc1(maskIn + w) : 0;
         }
-        int bit[K], len[K], cost[K], total[K], cnt[K], have[K], lsym[K], dsym[K];
-        bool undec[K], ok[K];
-        const uint32_t* wp[K];
-        uint32_t cur[K], nxt[K];
-        // stage B: costs (LDS lookups of K tokens overlap), stage C: first two words of each token's bytes
+        int bit[K], cost[K], lim[K];
+        bool undec[K], act[K];
+        D4GLitWalk lw[K];
+        // stage B: costs and the first two words of each record's bytes
 #pragma unroll
         for (int j = 0; j < K; j++) {
             bit[j] = (int)((mwv[j] >> lane) & 1);
-            uint32_t a = tokv[j].x;
-            int dist = tok_dist(a);
-            undec[j] = dist > 0 && !bit[j];
-            ok[j] = undec[j];
-            len[j] = tok_val(a);
-            total[j] = 0;
-            cnt[j] = 0;
+            uint32_t a = rv[j].x;
+            int len = ref_len(a);
+            act[j] = len > 0 && !bit[j];
+            undec[j] = act[j];
             cost[j] = 0;
-            lsym[j] = dsym[j] = 0;
-            cur[j] = nxt[j] = 0;
-            have[j] = 0;
-            wp[j] = nullptr;
-            if (undec[j]) {
-                cost[j] = backref_cost(S, len[j], tok_edge(a), dist, lsym[j], dsym[j]);
-                uintptr_t ad = (uintptr_t)(Ub + tokv[j].y);
-                wp[j] = (const uint32_t*)(ad & ~(uintptr_t)3);
-                int skip = (int)(ad & 3);
-                cur[j] = *wp[j]++ >> (8 * skip);
-                have[j] = 4 - skip;
-                nxt[j] = *wp[j]++;  // U is padded: reading one word past a short token is harmless
+            lim[j] = 0;
+            lw[j].widx = 0; lw[j].cur = lw[j].nxt = 0; lw[j].sh = 0; lw[j].rem = 0; lw[j].total = 0;
+            if (act[j]) {
+                cost[j] = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);  // getLitLenSize — :112-131
+                lim[j] = cost[j] + (prune ? 1 : 0);
+                lw_start(lw[j], Uw, rv[j].y, len);
             }
         }
-        // stage D: the K early-exit literal sums advance in lock step, one byte each per turn
-        while (undec[0] | undec[1] | undec[2] | undec[3]) {
+        // stage C: the K bounded literal sums advance in lock step, four bytes each per turn
+        while (true) {
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < K; j++) any |= undec[j];
+            if (!any) break;
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 if (undec[j]) {
-                    if (have[j] == 0) { cur[j] = nxt[j]; have[j] = 4; nxt[j] = *wp[j]++; }
-                    int bs = S->litLen[cur[j] & 0xff];
-                    cur[j] >>= 8;
-                    have[j]--;
-                    if (bs < 1) { ok[j] = false; undec[j] = false; }
-                    else {
-                        total[j] += bs;
-                        if (prune ? total[j] > cost[j] : total[j] >= cost[j]) { ok[j] = false; undec[j] = false; }
-                        else if (++cnt[j] == len[j]) undec[j] = false;
-                    }
+                    lw_step(lw[j], Uw, lc);
+                    if (lw[j].total >= lim[j] || lw[j].rem <= 0) undec[j] = false;
                 }
             }
         }
-        // stage E: apply, stage F: new mask words
+        // stage D: apply, new mask words
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            if (ok[j]) {
+            if (act[j] && lw[j].total < lim[j]) {
+                uint32_t a = rv[j].x;
                 bit[j] = 1;
-                savedLane += cost[j] - total[j];
-                atomicSub(&S->hist[lsym[j]], 1u);
-                atomicSub(&S->hist[D4G_NLIT + dsym[j]], 1u);
-                for_bytes(Ub + tokv[j].y, len[j], [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
+                savedLane += cost[j] - lw[j].total;
+                atomicSub(&S->hist[ref_lsym(a)], 1u);
+                atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
+                for_bytes(Ub + rv[j].y, ref_len(a), [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
             }
             uint64_t nm = __ballot(bit[j]);
             if (lane == 0 && w0 + j < nWords) st_sc1(maskOut + w0 + j, nm);
         }
     }
-    saved = wg_sum_i64((long long)savedLane, L->red);
+    long long saved = wg_sum_i64((long long)savedLane, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
     __syncthreads();
 }
@@ -202,72 +240,59 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
     __syncthreads();
     if (threadIdx.x < 64) L->misc[threadIdx.x] = 0;
     if (threadIdx.x < 4) flags[threadIdx.x] = 0;
-    __syncthreads();
+    wg_fill_lit_cost(L);
+    const uint16_t* lc = L->litCost;
+    const uint2* rf = c.refs + b.refStart;
+    const uint8_t* Ub = c.U + b.uBase;
+    const uint32_t* Uw = (const uint32_t*)Ub;
+    const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
     if (S->type == D4G_DYNAMIC) {
-        const uint2* tk = c.tok + b.tokStart;
-        uint2 ntok = make_uint2(0u, 0u);
+        uint2 nrv = make_uint2(0u, 0u);
         uint64_t nmw = 0;
-        if (wave < b.maskWords) {
-            long long t = (long long)wave * 64 + lane;
-            if (t < b.tokCount) ntok = tk[t];
+        if (wave < nWords) {
+            int r = wave * 64 + lane;
+            if (r < nRef) nrv = rf[r];
             nmw = ld_sc1(maskIn + wave);
         }
-        for (long long w = wave; w < b.maskWords; w += nw) {
-            uint2 cur = ntok;
+        for (int w = wave; w < nWords; w += nw) {
+            uint2 cur = nrv;
             uint64_t mw = nmw;
-            long long t = w * 64 + lane;
-            long long w2 = w + nw;
-            if (w2 < b.maskWords) {
-                long long t2 = w2 * 64 + lane;
-                ntok = t2 < b.tokCount ? tk[t2] : make_uint2(0u, 0u);
+            int w2 = w + nw;
+            if (w2 < nWords) {
+                int r2 = w2 * 64 + lane;
+                nrv = r2 < nRef ? rf[r2] : make_uint2(0u, 0u);
                 nmw = ld_sc1(maskIn + w2);
             }
-            int len = 0, cost = 0, bin = 0;
-            long long off = 0;
-            bool act = false;
-            if (t < b.tokCount && !((mw >> lane) & 1)) {
-                uint32_t a = cur.x;
-                int dist = tok_dist(a);
-                if (dist > 0) {
-                    int lsym, dsym;
-                    len = tok_val(a);
-                    cost = backref_cost(S, len, tok_edge(a), dist, lsym, dsym);
-                    bin = lsym - 257;
-                    off = cur.y;
-                    act = true;
-                    atomicOr(&flags[1], 1u << bin);
-                }
+            uint32_t a = cur.x;
+            int len = ref_len(a), cost = 0, bin = 0;
+            bool act = len > 0 && !((mw >> lane) & 1);
+            if (act) {
+                cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
+                bin = ref_lsym(a) - 257;
+                atomicOr(&flags[1], 1u << bin);
             }
             int total = 0;
-            bool ok = true;
             if (act && len <= D4G_LONG_TOKEN) {
-                for_bytes(c.U + b.uBase + off, len, [&](int by) {
-                    int bs = S->litLen[by];
-                    if (bs < 1) { ok = false; return false; }
-                    total += bs;
-                    return true;
-                });
+                D4GLitWalk lw;
+                lw_start(lw, Uw, cur.y, len);
+                while (lw.rem > 0) lw_step(lw, Uw, lc);
+                total = lw.total;
             }
-            // long back-references: the whole wave sums one token at a time (coalesced byte loads)
+            // long back-references: the whole wave sums one record at a time (coalesced byte loads)
             unsigned long long ml = __ballot(act && len > D4G_LONG_TOKEN);
             while (ml) {
                 int srcLane = __ffsll((long long)ml) - 1;
                 ml &= ml - 1;
-                long long o2 = __shfl(off, srcLane);
+                uint32_t o2 = __shfl(cur.y, srcLane);
                 int l2 = __shfl(len, srcLane);
-                const uint8_t* p2 = c.U + b.uBase + o2;
-                int tsum = 0, bad = 0;
-                for (int k = lane; k < l2; k += 64) {
-                    int bs = S->litLen[p2[k]];
-                    bad |= bs < 1;
-                    tsum += bs;
-                }
+                const uint8_t* p2 = Ub + o2;
+                int tsum = 0;
+                for (int k = lane; k < l2; k += 64) tsum += lc[p2[k]];
                 tsum = (int)wave_sum_i64(tsum);
-                unsigned long long mb = __ballot(bad);
-                if (lane == srcLane) { total = tsum; ok = mb == 0; }
+                if (lane == srcLane) total = tsum;
             }
             if (act) {
-                if (!ok) atomicOr(&flags[0], 1u << bin);
+                if (total >= D4G_NO_CODE) atomicOr(&flags[0], 1u << bin);   // a byte without a code: the bin is not allowed
                 else { atomicAdd(&binSize[bin], total - cost); atomicAdd(&binFreq[bin], 1); }
             }
         }
@@ -286,52 +311,28 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
     }
     __syncthreads();
     int rem = (int)flags[2] - 1;
-    const uint2* tk2 = c.tok + b.tokStart;
-    uint2 ntok2 = make_uint2(0u, 0u);
-    uint64_t nmw2 = 0;
-    if (wave < b.maskWords) {
-        long long t = (long long)wave * 64 + lane;
-        if (t < b.tokCount) ntok2 = tk2[t];
-        nmw2 = ld_sc1(maskIn + wave);
-    }
-    for (long long w = wave; w < b.maskWords; w += nw) {
-        uint2 cur = ntok2;
-        uint64_t mw = nmw2;
-        long long t = w * 64 + lane;
-        long long w2 = w + nw;
-        if (w2 < b.maskWords) {
-            long long t2 = w2 * 64 + lane;
-            ntok2 = t2 < b.tokCount ? tk2[t2] : make_uint2(0u, 0u);
-            nmw2 = ld_sc1(maskIn + w2);
-        }
+    for (int w = wave; w < nWords; w += nw) {
+        int r = w * 64 + lane;
+        uint2 cur = r < nRef ? rf[r] : make_uint2(0u, 0u);
+        uint64_t mw = ld_sc1(maskIn + w);
         int bit = (int)((mw >> lane) & 1);
-        int len = 0;
-        long long off = 0;
-        bool hit = false;
-        if (rem >= 0 && t < b.tokCount && !bit) {
-            uint32_t a = cur.x;
-            int dist = tok_dist(a);
-            if (dist > 0) {
-                len = tok_val(a);
-                int lsym = d4g_len2sym(len, tok_edge(a));
-                if (lsym - 257 == rem) {
-                    bit = 1;
-                    hit = true;
-                    off = cur.y;
-                    atomicSub(&S->hist[lsym], 1u);
-                    atomicSub(&S->hist[D4G_NLIT + d4g_dist2sym(dist)], 1u);
-                }
-            }
+        uint32_t a = cur.x;
+        int len = ref_len(a);
+        bool hit = rem >= 0 && len > 0 && !bit && ref_lsym(a) - 257 == rem;
+        if (hit) {
+            bit = 1;
+            atomicSub(&S->hist[ref_lsym(a)], 1u);
+            atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
         }
         if (hit && len <= D4G_LONG_TOKEN)
-            for_bytes(c.U + b.uBase + off, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
+            for_bytes(Ub + cur.y, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
         unsigned long long ml = __ballot(hit && len > D4G_LONG_TOKEN);
         while (ml) {
             int srcLane = __ffsll((long long)ml) - 1;
             ml &= ml - 1;
-            long long o2 = __shfl(off, srcLane);
+            uint32_t o2 = __shfl(cur.y, srcLane);
             int l2 = __shfl(len, srcLane);
-            const uint8_t* p2 = c.U + b.uBase + o2;
+            const uint8_t* p2 = Ub + o2;
             for (int k = lane; k < l2; k += 64) atomicAdd(&S->hist[p2[k]], 1u);
         }
         uint64_t nm = __ballot(bit);

@@ -43,12 +43,12 @@ struct D4GProbeOut {
     long long nTok, uLen, sizeBits;
     long long needHist;    // max over back-references of (distance - bytes produced so far in the block)
     int32_t nCp;           // checkpoints recorded
-    int32_t pad;
+    int32_t nRef;          // back-reference tokens in the block
 };
 // Probes leave up to 32 checkpoints per block (token boundaries with their bit position and running
 // token / byte counts) so that the emit pass can decode a block's segments in parallel.
 #define D4G_MAXCP 32
-struct D4GCheckpoint { long long bitPos; unsigned nTok; unsigned nU; };
+struct D4GCheckpoint { long long bitPos; unsigned nTok; unsigned nU; unsigned nRef; unsigned pad; };
 struct D4GCpSet { int32_t n; int32_t pad; D4GCheckpoint cp[D4G_MAXCP]; };
 
 struct D4GEmitIn {
@@ -61,6 +61,7 @@ struct D4GEmitIn {
     long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
     long long sizeBits;    // from the probe
     long long cpIndex;     // index of the block's checkpoint set (-1: none, the block is one segment)
+    long long refStart;    // absolute index of the block's first back-reference record
     int32_t nCp;
     int32_t pad;
 };
@@ -69,7 +70,7 @@ struct D4GEmitSeg { int32_t emit; int32_t seg; };  // segment `seg` (0..nCp) of 
 struct D4GSegCtl {
     int mode;              // 0 whole block; 1 header only (write the block's state with an empty histogram); 2 one segment
     long long startBit;    // mode 2, seg > 0: first bit of the segment (a token boundary)
-    unsigned startTok, startU;
+    unsigned startTok, startU, startRef;
     long long endBit;      // mode 2: stop at this token boundary (-1: run to EOB)
     D4GCpSet* cpOut;       // mode 0, probe: where to leave the checkpoints (may be null)
 };
@@ -273,6 +274,8 @@ struct D4GParseOut {
     uint2* tok;
     uint8_t* U;
     D4GState* states;
+    uint2* refs;        // back-reference records (d4g_types.h), in token order
+    uint32_t* tokRef;   // per token: index of its back-reference record (written for back-references only)
 };
 
 template <bool EMIT>
@@ -297,7 +300,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         long long e = sc.endBit - base * 8;
         segEndRel = (sc.mode == 2 && sc.endBit >= 0) ? (e > 0x3fffffff ? 0x3fffffff : (int)e) : 0x7fffffff;
     };
-    po.nCp = 0; po.pad = 0;
+    po.nCp = 0; po.nRef = 0;
     po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
     stage(bitPos);
     long long pk = 0;
@@ -446,14 +449,18 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     }
     // ---- decodeStream — DeflateBlockHuffman.java:778-890: lane 0 decodes, the wave refills the input chunk ----
     // 32-bit counters inside the loop: a block's tokens, bytes and bits fit comfortably
-    unsigned litlenBits = 0, nTok = 0, nU = 0;
+    unsigned litlenBits = 0, nTok = 0, nU = 0, nRef = 0;
     int needHist = 0;
     uint2* tokOut = EMIT ? out.tok + em->tokStart : nullptr;
+    uint2* refOut = EMIT ? out.refs + em->refStart : nullptr;
+    uint32_t* tokRefOut = EMIT ? out.tokRef + em->tokStart : nullptr;
+    const uint32_t refBase32 = EMIT ? (uint32_t)em->refStart : 0u;
     const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
     if (EMIT && sc.mode == 2) {
         if (sc.startBit >= 0) stage(sc.startBit);   // segment > 0 starts at a checkpoint; segment 0 right after the header
         nTok = sc.startTok;
         nU = sc.startU;
+        nRef = sc.startRef;
     }
     // probe: checkpoints every `cpSpacing` tokens; when the set is full every other one is dropped
     unsigned cpSpacing = 1024, nextCp = 1024;
@@ -479,6 +486,8 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                             L.cps.cp[nCp].bitPos = br.pos();
                             L.cps.cp[nCp].nTok = nTok;
                             L.cps.cp[nCp].nU = nU;
+                            L.cps.cp[nCp].nRef = nRef;
+                            L.cps.cp[nCp].pad = 0;
                             nCp++;
                         }
                     }
@@ -511,7 +520,12 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                     br.skip(dcl + deb);
                     used += dcl + deb;
                     if (nU < 32768u && dist - (int)nU > needHist) needHist = dist - (int)nU;  // only the block's first 32 KiB can reach back past its start
-                    if (EMIT) { S->hist[sym]++; S->hist[D4G_NLIT + ds]++; }
+                    if (EMIT) {
+                        S->hist[sym]++; S->hist[D4G_NLIT + ds]++;
+                        refOut[nRef] = make_uint2(d4g_ref_pack(len, sym, ds, eb + deb), uStart32 + nU);
+                        tokRefOut[nTok] = refBase32 + nRef;
+                    }
+                    nRef++;
                     val = len;
                 }
                 litlenBits += (unsigned)used;
@@ -564,6 +578,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     po.uLen = (long long)__shfl(nU, 0);
     po.sizeBits = S->sizeBits;
     po.needHist = (long long)__shfl(needHist, 0);
+    po.nRef = (int32_t)__shfl(nRef, 0);
     if (EMIT) {
         D4GState* g = out.states + em->stateIdx;
         for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
@@ -575,8 +590,8 @@ __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* stream
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
-    D4GParseOut none = {nullptr, nullptr, nullptr};
-    D4GSegCtl sc = {0, -1, 0u, 0u, -1, cpPool ? cpPool + blockIdx.x : nullptr};
+    D4GParseOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    D4GSegCtl sc = {0, -1, 0u, 0u, 0u, -1, cpPool ? cpPool + blockIdx.x : nullptr};
     d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none, sc);
     if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
 }
@@ -586,7 +601,7 @@ __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* stream
 __global__ void __launch_bounds__(64) k_emit_init(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
     const D4GEmitIn em = in[blockIdx.x];
     D4GProbeOut po;
-    D4GSegCtl sc = {1, -1, 0u, 0u, -1, nullptr};
+    D4GSegCtl sc = {1, -1, 0u, 0u, 0u, -1, nullptr};
     d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, sc);
     if ((threadIdx.x & 63) == 0 && (po.status != 0 || (em.type == D4G_STORED && po.uLen != em.uLen))) atomicAdd(errors, 1);
 }
@@ -595,10 +610,10 @@ __global__ void __launch_bounds__(64) k_emit_segments(const D4GStreamDesc* strea
                                                       const D4GCpSet* cpPool, D4GParseOut out, int32_t* errors) {
     const D4GEmitSeg sg = segs[blockIdx.x];
     const D4GEmitIn em = in[sg.emit];
-    D4GSegCtl sc = {2, -1, 0u, 0u, -1, nullptr};
+    D4GSegCtl sc = {2, -1, 0u, 0u, 0u, -1, nullptr};
     if (em.cpIndex >= 0) {
         const D4GCpSet* cs = cpPool + em.cpIndex;
-        if (sg.seg > 0) { sc.startBit = cs->cp[sg.seg - 1].bitPos; sc.startTok = cs->cp[sg.seg - 1].nTok; sc.startU = cs->cp[sg.seg - 1].nU; }
+        if (sg.seg > 0) { sc.startBit = cs->cp[sg.seg - 1].bitPos; sc.startTok = cs->cp[sg.seg - 1].nTok; sc.startU = cs->cp[sg.seg - 1].nU; sc.startRef = cs->cp[sg.seg - 1].nRef; }
         if (sg.seg < em.nCp) sc.endBit = cs->cp[sg.seg].bitPos;
     }
     D4GProbeOut po;

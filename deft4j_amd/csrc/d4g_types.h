@@ -10,9 +10,14 @@
 //             .x  literal byte | 256 (EOB) | match length, dist << 16 (0 for literals/EOB),
 //                 bit 15 = the 284-as-258 edge case (DeflateBlockHuffman.java:843)
 //             .y  offset of the token's decoded bytes in U (the stream's decoded data)
+//   refs[r]   2 x u32, one record per back-reference token, in token order (the search's token passes
+//             read only these — literals never change):
+//             .x  length | (length symbol - 257) << 9 | distance symbol << 14 | extra bits << 19
+//             .y  offset of its decoded bytes in U
+//   tokRef[t] u32  index into refs of back-reference token t (the writer's way from a token to its mask bit)
 //   U[]       u8   decoded bytes of the whole stream, block after block
 //   State     ~3.3 KB per candidate: code lengths, header RLE pairs, symbol histogram, sizes
-//   masks     1 bit per token: "this back-reference is expanded to literals".  The reference
+//   masks     1 bit per back-reference: "this back-reference is expanded to literals".  The reference
 //             only ever turns back-references into literals (replaceWithLiteralsIfSmaller
 //             :222-296, removeDistLitLeastExpensive :373-458), never the reverse, so every
 //             token list the search visits is the block's token range plus such a mask.
@@ -61,7 +66,9 @@ struct D4GBlock {
     int64_t sizeBits;    // encoded size without the 3 prolog bits (stored: without alignment)
     int64_t stateIdx;    // index of the block's current state in the block-state array
     int64_t maskBase;    // first u64 word of this block's mask pool
-    int64_t maskWords;   // u64 words per mask = ceil(tokCount / 64)
+    int64_t maskWords;   // u64 words per mask = ceil(refCount / 64)
+    int64_t refStart;    // first back-reference record (index into refs); adjacent blocks are contiguous
+    int64_t refCount;
 };
 
 // Ops of the candidate-search program (one optimiseBlock call = one program run per block).

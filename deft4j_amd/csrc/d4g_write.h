@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs
             if (dist == 0) {
                 if (val == 256 && t != b.tokCount - 1) kind = 0;  // EOB of a merged-away block
                 else { kind = 1; nbits = S->litLen[val]; }
-            } else if ((mask[t >> 6] >> (t & 63)) & 1) {
+            } else if (d4g_ref_expanded(mask, c.tokRef[b.tokStart + t], b.refStart)) {
                 kind = 3;
                 const uint8_t* p = Ub + toff;
                 for_bytes(p, val, [&](int by) { nbits += S->litLen[by]; return true; });
@@ -221,12 +221,12 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
     if (wasType == D4G_FIXED && threadIdx.x == 0) S->type = D4G_DYNAMIC;  // force the full recompute below
     __syncthreads();
     wg_recode_to_fixed(&L);
-    // masks: tokens of A then tokens of B
+    // masks: back-references of A then those of B
     const uint64_t* mA = mask_ptr(c, bA, sA->maskSlot);
     const uint64_t* mB = mask_ptr(c, bB, sB->maskSlot);
     uint64_t* mM = mask_ptr(c, bM, 0);
-    long long q = bA.tokCount >> 6;
-    int s = (int)(bA.tokCount & 63);
+    long long q = bA.refCount >> 6;
+    int s = (int)(bA.refCount & 63);
     for (long long w = threadIdx.x; w < bM.maskWords; w += blockDim.x) {
         uint64_t v;
         if (w < q) v = mA[w];
