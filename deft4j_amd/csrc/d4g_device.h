@@ -152,6 +152,10 @@ struct TreeMem {
     }
 };
 
+template <typename H, typename I, int MAXN, typename OutFn>
+__device__ int d4g_tree_finish(TreeMem<H, I, MAXN>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
+                               OutFn outLen);
+
 // Returns 0 on success, 1 if the limiter could not rebalance (the reference throws there).
 // freq(i) reads symbol i's frequency; outLen(i, len) receives each symbol's code length.
 template <typename H, typename I, int MAXN, typename FreqFn, typename OutFn>
@@ -230,6 +234,18 @@ __device__ int d4g_build_tree(TreeMem<H, I, MAXN>& m, int stride, int lane, int 
         pq_add((((hl >> IDB) + (hr >> IDB)) << IDB) | (H)id);
     }
     int root = (int)(pq_remove() & IDMASK);
+#undef TM
+    return d4g_tree_finish(m, stride, lane, nl, root, numSymbols, limit, outLen);
+}
+
+// Second half of the builder: depths by DFS (traverse :134-158), the depth limiter (:75-127) and the
+// lengths (getTable :164-192) of a tree whose nodes are already in m.left / right / parent / value.
+template <typename H, typename I, int MAXN, typename OutFn>
+__device__ int d4g_tree_finish(TreeMem<H, I, MAXN>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
+                               OutFn outLen) {
+    const int NONE = TreeMem<H, I, MAXN>::NONE;
+    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
+#define TM(arr, i) m.arr[(i) * stride + lane]
     int maxDepth = 0;
     // traverse — DFS, left before right; records each leaf's depth and the first leaf per depth
     auto traverse = [&]() {
@@ -284,6 +300,162 @@ __device__ int d4g_build_tree(TreeMem<H, I, MAXN>& m, int stride, int lane, int 
     }
 #undef TM
     return err;
+}
+
+// ---------------------------------------------------------------------------------------
+// The same tree built by one whole wave.  The first 64 slots of the priority queue (its top six
+// levels, where every sift passes) live in a register pair: slot k is lane k of `w0` (weight) and `i0`
+// (node id), read with v_readlane at a wave-uniform index and written with a compare + select, so those
+// sift steps cost no LDS round trip; deeper slots stay in LDS (m.heap).  Every lane runs the same code on
+// the same wave-uniform values, which keeps the queue's control flow on the scalar unit; lane 0 records
+// the tree's nodes in LDS.  Leaf depths are then counted by one lane per leaf; only a tree deeper than
+// `limit` goes through the serial DFS + limiter of d4g_tree_finish.
+// ---------------------------------------------------------------------------------------
+#define D4G_LAMBDA_INLINE __attribute__((always_inline))
+#ifdef D4G_HOSTSIM
+D4G_DEV int d4g_readlane(int v, int k) { return __shfl(v, k); }
+D4G_DEV int d4g_uniform(int v) { return __shfl(v, 0); }
+#else
+D4G_DEV int d4g_readlane(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+D4G_DEV int d4g_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+struct D4GWaveHeap {
+    int w0, i0;
+    uint64_t* deep;   // LDS, slots >= 64: weight << 32 | id
+    D4G_DEV void get(int k, unsigned& ww, int& ii) const {
+        if (k < 64) { ww = (unsigned)d4g_readlane(w0, k); ii = d4g_readlane(i0, k); }
+        else {
+            uint64_t e = deep[k];
+            ww = (unsigned)d4g_uniform((int)(e >> 32));
+            ii = d4g_uniform((int)(uint32_t)e);
+        }
+    }
+    D4G_DEV void put(int k, unsigned ww, int ii) {
+        const int lane = threadIdx.x & 63;
+        if (k < 64) { w0 = lane == k ? (int)ww : w0; i0 = lane == k ? ii : i0; }
+        else if (lane == 0) deep[k] = ((uint64_t)ww << 32) | (uint32_t)ii;
+    }
+};
+
+// All 64 lanes of one wave call this with the same arguments.  NREG = ceil(MAXN / 64).
+template <int NREG, typename H, typename I, int MAXN, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN>& m, int numSymbols, int limit, FreqFn freq, OutFn outLen) {
+    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
+    const int lane = threadIdx.x & 63;
+    numSymbols = d4g_uniform(numSymbols);  // tell the compiler what is wave-uniform: the queue code then runs on the scalar unit
+    limit = d4g_uniform(limit);
+    D4GWaveHeap hp;
+    hp.w0 = 0; hp.i0 = 0;
+    hp.deep = (uint64_t*)m.heap;
+    int nl = 0, hs = 0;
+    // java.util.PriorityQueue.offer / poll, as in d4g_build_tree
+    auto pq_add = [&](unsigned wx, int idx) D4G_LAMBDA_INLINE {
+        int k = hs++;
+        while (k > 0) {
+            int p = (k - 1) >> 1;
+            unsigned pw; int pi;
+            hp.get(p, pw, pi);
+            if (wx >= pw) break;
+            hp.put(k, pw, pi);
+            k = p;
+        }
+        hp.put(k, wx, idx);
+    };
+    auto pq_remove = [&](unsigned& rw, int& ri) D4G_LAMBDA_INLINE {
+        hp.get(0, rw, ri);
+        int s = --hs;
+        if (s != 0) {
+            unsigned xw; int xi;
+            hp.get(s, xw, xi);
+            int k = 0, half = s >> 1;
+            while (k < half) {
+                int child = 2 * k + 1;
+                unsigned cw; int ci;
+                hp.get(child, cw, ci);
+                if (child + 1 < s) {
+                    unsigned rw2; int ri2;
+                    hp.get(child + 1, rw2, ri2);
+                    if (cw > rw2) { cw = rw2; ci = ri2; child = child + 1; }
+                }
+                if (xw <= cw) break;
+                hp.put(k, cw, ci);
+                k = child;
+            }
+            hp.put(k, xw, xi);
+        }
+    };
+    // leaves in symbol order: 64 frequencies per step, the used ones are offered one by one
+    for (int base = 0; base < numSymbols; base += 64) {
+        int i = base + lane;
+        int fv = i < numSymbols ? (int)freq(i) : 0;
+        unsigned long long um = __ballot(fv != 0);
+        while (um) {
+            int bpos = __ffsll((long long)um) - 1;
+            um &= um - 1;
+            unsigned f = (unsigned)d4g_readlane(fv, bpos);
+            if (lane == 0) m.value[nl] = (I)(base + bpos);
+            pq_add(f, nl);
+            nl++;
+        }
+    }
+    int index = 0;
+    while (hs < 2) {  // dummy leaves — HuffmanTree.java:50-58
+        bool unused = index >= numSymbols;
+        if (!unused) unused = d4g_uniform((int)freq(index)) == 0;
+        if (unused) {
+            if (lane == 0) m.value[nl] = (I)index;
+            pq_add(1u, nl);
+            nl++;
+        }
+        index++;
+    }
+    int nn = nl;
+    for (int i = 0; i < nl - 1; i++) {
+        unsigned lw, rw;
+        int l, r;
+        pq_remove(lw, l);
+        pq_remove(rw, r);
+        int id = nn++;
+        if (lane == 0) {
+            m.left[id - nl] = (I)l;
+            m.right[id - nl] = (I)r;
+            m.parent[l] = (I)id;
+            m.parent[r] = (I)(id | SIDE);
+        }
+        pq_add(lw + rw, id);
+    }
+    unsigned rootW;
+    int root;
+    pq_remove(rootW, root);
+    // leaf depths: one lane per leaf walks to the root
+    int dep[NREG];
+    int maxDepth = 0;
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+        int leaf = r * 64 + lane, d = 0;
+        if (leaf < nl) {
+            int node = leaf;
+            while (node != root) { node = m.parent[node] & ~SIDE; d++; }
+        }
+        dep[r] = d;
+        maxDepth = d > maxDepth ? d : maxDepth;
+    }
+    maxDepth = wave_max_i32(maxDepth);
+    if (maxDepth > limit) {
+        int err = 0;
+        if (lane == 0) err = d4g_tree_finish(m, 1, 0, nl, root, numSymbols, limit, outLen);
+        return __shfl(err, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+        int leaf = r * 64 + lane;
+        if (leaf < nl) {
+            int v = m.value[leaf];
+            if (v < numSymbols) outLen(v, dep[r]);
+        }
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

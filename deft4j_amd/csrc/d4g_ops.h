@@ -51,7 +51,7 @@ struct D4GLds {
     alignas(16) unsigned char treeLit[TreeMem<uint64_t, uint16_t, D4G_NLIT>::bytes(1)];
     alignas(16) unsigned char treeDist[TreeMem<uint64_t, uint16_t, D4G_NDIST>::bytes(1)];
     alignas(16) unsigned char treeCl[TreeMem<uint32_t, uint8_t, 20>::bytes(1)];
-    uint16_t clFreq[20];
+    uint32_t clFreq[20];
     uint16_t litCost[256];    // bits of each literal under the state's code; absent symbols cost D4G_NO_CODE
 };
 
@@ -365,36 +365,74 @@ __device__ void t0_remove_trailing_header_codes(D4GState* S) {
     S->hdrBits -= saved;
 }
 
-// rewriteHeader — DeflateBlockHuffman.java:484-577.  Thread 0 (the pair list is sequential).
-__device__ void t0_rewrite_header(D4GLds* L, int flags) {
+// rewriteHeader — DeflateBlockHuffman.java:484-577 (HuffmanTable.packCodeLengths :100-186 inside).  All threads.
+// Wave 0 finds the runs of the concatenated code lengths with ballots; the lane at each run start packs
+// that run (the pair count first, then the pairs at their prefix-summed position).  Thread 0 finishes with
+// the code-length code and the header size.
+__device__ void wg_rewrite_header(D4GLds* L, int flags) {
     D4GState* S = &L->st;
+    __syncthreads();
     if (S->type != D4G_DYNAMIC) return;
-    S->sizeBits -= S->hdrBits;
-    for (int i = 0; i < 19; i++) L->clFreq[i] = 0;
-    int np = 0;
-    int nLit = S->nLit, n = S->nLit + S->nDist;
-    d4g_for_runs(n, [&](int i) { return i < nLit ? (int)S->litLen[i] : (int)S->distLen[i - nLit]; },
-                 [&](int v, int r) {
-                     d4g_pack_run(v, r, flags, [&](int sym, int run, int value) {
-                         S->pairs[np++] = pair_encode(sym, run, value);
-                         L->clFreq[sym]++;
-                     });
-                 });
-    S->nPairs = np;
-    t0_build_cl_tree(L);
-    S->nCl = 19;
-    long long hb = 5 + 5 + 4 + 19 * 3;
-    for (int s = 0; s < 19; s++) hb += (long long)L->clFreq[s] * (S->clLen[s] + (s >= 16 ? pair_extra_bits(s) : 0));
-    S->hdrBits = hb;
-    S->sizeBits += hb;
-#ifdef D4G_HOSTSIM
-    if (getenv("D4G_DEBUG2")) {
-        fprintf(stderr, "rewrite flags %d n %d np %d hb %lld freq:", flags, n, np, hb);
-        for (int s2 = 0; s2 < 19; s2++) fprintf(stderr, " %d/%d", L->clFreq[s2], S->clLen[s2]);
-        fprintf(stderr, "\n");
+    if (threadIdx.x < 20) L->clFreq[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int nLit = S->nLit, n = nLit + S->nDist;
+        auto len = [&](int i) { return i < nLit ? (int)S->litLen[i] : (int)S->distLen[i - nLit]; };
+        constexpr int NCH = (D4G_NLIT + D4G_NDIST) / 64;  // 5 chunks of 64 code lengths
+        unsigned long long sm[NCH];
+        int v[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            int i = ch * 64 + lane;
+            v[ch] = i < n ? len(i) : -1;
+            int pv = (i > 0 && i < n) ? len(i - 1) : -2;
+            sm[ch] = __ballot(i < n && v[ch] != pv);   // runs may span the literal/distance boundary — A.4
+        }
+        int base = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            int i = ch * 64 + lane;
+            bool start = (sm[ch] >> lane) & 1;
+            int cnt = 0, run = 0;
+            if (start) {
+                int nx = -1;
+                unsigned long long m = lane == 63 ? 0ULL : (sm[ch] >> (lane + 1));
+                if (m) nx = i + __ffsll((long long)m);
+#pragma unroll
+                for (int c2 = ch + 1; c2 < NCH; c2++)
+                    if (nx < 0 && sm[c2]) nx = c2 * 64 + __ffsll((long long)sm[c2]) - 1;
+                if (nx < 0) nx = n;
+                run = nx - i;
+                d4g_pack_run(v[ch], run, flags, [&](int, int, int) { cnt++; });
+            }
+            int incl = cnt;
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            int off = base + incl - cnt;
+            if (start)
+                d4g_pack_run(v[ch], run, flags, [&](int sym, int r, int value) {
+                    S->pairs[off++] = pair_encode(sym, r, value);
+                    atomicAdd(&L->clFreq[sym], 1u);
+                });
+            base += __shfl(incl, 63);
+        }
+        if (lane == 0) S->nPairs = base;
     }
-#endif
-    t0_remove_trailing_header_codes(S);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->sizeBits -= S->hdrBits;
+        t0_build_cl_tree(L);
+        S->nCl = 19;
+        long long hb = 5 + 5 + 4 + 19 * 3;
+        for (int s = 0; s < 19; s++) hb += (long long)L->clFreq[s] * (S->clLen[s] + (s >= 16 ? pair_extra_bits(s) : 0));
+        S->hdrBits = hb;
+        S->sizeBits += hb;
+        t0_remove_trailing_header_codes(S);
+    }
+    __syncthreads();
 }
 
 // replaceRLERunsWithLiteralsIfSmaller — DeflateBlockHuffman.java:321-332.  All threads.
@@ -480,9 +518,12 @@ __device__ void wg_litlen_bits_from_hist(D4GLds* L) {
 }
 
 // recodeHuffman — DeflateBlockHuffman.java:670-743 + recodeToHuffman :745-757
-__device__ void wg_recode_huffman(D4GLds* L) {
+__device__ void wg_recode_huffman(D4GLds* L, long long* prof = nullptr) {
     D4GState* S = &L->st;
     __syncthreads();
+#ifdef D4G_PROFILE_OPS
+    long long pt0 = clock64(), pt1 = 0, pt2 = 0;
+#endif
     int ml = 0, md = 0;
     for (int i = threadIdx.x; i < 286; i += blockDim.x)
         if (S->hist[i]) ml = i + 1 > ml ? i + 1 : ml;
@@ -493,6 +534,41 @@ __device__ void wg_recode_huffman(D4GLds* L) {
     for (int i = threadIdx.x; i < D4G_NLIT; i += blockDim.x) S->litLen[i] = 0;
     for (int i = threadIdx.x; i < D4G_NDIST; i += blockDim.x) S->distLen[i] = 0;
     __syncthreads();
+#if !defined(D4G_HOSTSIM) || defined(D4G_SIM_WAVE_HEAP)
+    // wave 0 builds the literal/length tree while wave 1 (when there is one) builds the distance tree
+    const int wv = d4g_uniform((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63;
+    if (wv == 0) {
+        TreeMem<uint64_t, uint16_t, D4G_NLIT> tm;
+        tm.carve(L->treeLit, 1);
+        int err = d4g_build_tree_wave<(D4G_NLIT + 63) / 64>(tm, lastLit, 15, [&](int i) { return S->hist[i]; },
+                                                            [&](int v, int len) { S->litLen[v] = (uint8_t)len; });
+        if (ln == 0) {
+            if (err) atomicOr((unsigned*)&S->flags, 0x100u);
+            S->nLit = lastLit;
+        }
+#ifdef D4G_PROFILE_OPS
+        pt1 = clock64();
+#endif
+    }
+    if (wv == (blockDim.x > 64 ? 1 : 0)) {
+        bool used = ln < lastDist && S->hist[D4G_NLIT + ln] != 0;
+        int nz = __popcll(__ballot(used));
+        if (lastDist == 0) {  // handleZero: new HuffmanTable(1)
+            if (ln == 0) S->nDist = 1;
+        } else if (nz <= 1) {  // handleOne: one used distance code, length 1
+            if (ln == 0) { S->nDist = lastDist; S->distLen[lastDist - 1] = 1; }
+        } else {
+            TreeMem<uint64_t, uint16_t, D4G_NDIST> tm;
+            tm.carve(L->treeDist, 1);
+            int err = d4g_build_tree_wave<1>(tm, lastDist, 15, [&](int i) { return S->hist[D4G_NLIT + i]; },
+                                             [&](int v, int len) { S->distLen[v] = (uint8_t)len; });
+            if (ln == 0) {
+                if (err) atomicOr((unsigned*)&S->flags, 0x100u);
+                S->nDist = lastDist;
+            }
+        }
+    }
+#else
     if (threadIdx.x == 0) {
         TreeMem<uint64_t, uint16_t, D4G_NLIT> tm;
         tm.carve(L->treeLit, 1);
@@ -500,6 +576,9 @@ __device__ void wg_recode_huffman(D4GLds* L) {
                                  [&](int v, int len) { S->litLen[v] = (uint8_t)len; });
         if (err) atomicOr((unsigned*)&S->flags, 0x100u);
         S->nLit = lastLit;
+#ifdef D4G_PROFILE_OPS
+        pt1 = clock64();
+#endif
     }
     if (threadIdx.x == 64 || (blockDim.x <= 64 && threadIdx.x == 0)) {
         int nz = 0;
@@ -518,13 +597,24 @@ __device__ void wg_recode_huffman(D4GLds* L) {
             S->nDist = lastDist;
         }
     }
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         if (S->type != D4G_DYNAMIC) { S->type = D4G_DYNAMIC; S->hdrBits = 0; S->nPairs = 0; S->nCl = 0; }
     }
+#ifdef D4G_PROFILE_OPS
+    pt2 = clock64();
+#endif
     wg_litlen_bits_from_hist(L);
-    if (threadIdx.x == 0) t0_rewrite_header(L, F_DEFAULT);
-    __syncthreads();
+    wg_rewrite_header(L, F_DEFAULT);
+#ifdef D4G_PROFILE_OPS
+    if (threadIdx.x == 0 && prof) {
+        atomicAdd((unsigned long long*)&prof[24], (unsigned long long)(pt1 - pt0));          // literal/length tree (thread 0)
+        atomicAdd((unsigned long long*)&prof[25], (unsigned long long)(pt2 - pt1));          // wait for the distance tree
+        atomicAdd((unsigned long long*)&prof[26], (unsigned long long)(clock64() - pt2));    // sizes + header rewrite
+        atomicAdd((unsigned long long*)&prof[27], 1ULL);
+    }
+#endif
 }
 
 // recodeToFixedHuffman — DeflateBlockHuffman.java:637-653
@@ -696,7 +786,7 @@ __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId)
             wg_replace_backrefs(L, c, b, maskIn, mo, true);
             if (threadIdx.x == 0) S->maskSlot = op.maskSlot;
         }
-        wg_recode_huffman(L);
+        wg_recode_huffman(L, c.opStats);
         break;
     }
     case OP_RECODE_FULL: {  // recodedHuffmanFull — DeflateStream.java:212-229
@@ -707,7 +797,7 @@ __device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId)
             int ms = op.scratchMask + (it & 1);
             const uint64_t* mi = mask_ptr(c, b, S->maskSlot);
             wg_replace_backrefs(L, c, b, mi, mask_ptr(c, b, ms), true);
-            wg_recode_huffman(L);
+            wg_recode_huffman(L, c.opStats);
             __syncthreads();
             long long thisSize = S->sizeBits;
             __syncthreads();
@@ -990,8 +1080,7 @@ __global__ void __launch_bounds__(256) k_select(D4GCtx c, D4GRoundResult* result
         int slot = (op.kind == OP_CAND || op.kind == OP_HDRSEARCH) ? op.src : op.dst;
         wg_load_state(S, state_ptr(c, blk, slot));
         if (op.kind == OP_HDRSEARCH) {
-            if (threadIdx.x == 0) t0_rewrite_header(&L, c.hdrFlags[lane]);
-            __syncthreads();
+            wg_rewrite_header(&L, c.hdrFlags[lane]);
             if (c.hdrPrune[lane]) { wg_replace_rle_runs(&L, true); wg_recode_header(&L); }
             wg_optimise_header(&L);
             if (threadIdx.x == 0 && S->sizeBits != bestSize) {

@@ -25,6 +25,9 @@ names = {1: "OPT", 2: "RECODE", 3: "FULL", 4: "LEAST", 5: "POST", 6: "PRUNEHDR",
 print("ms_optimise %.1f state_ms %.1f" % (st["ms_optimise"], st["ms_state_kernels"]))
 if buf[23]:
     print("OPT sections (mean cycles): load %.0f  token pass %.0f  optimise_header %.0f" % (buf[20] / buf[23], buf[21] / buf[23], buf[22] / buf[23]))
+if buf[27]:
+    print("recode_huffman sections (mean cycles): lit tree %.0f  dist-tree wait %.0f  sizes+header %.0f  (n=%d)"
+          % (buf[24] / buf[27], buf[25] / buf[27], buf[26] / buf[27], buf[27]))
 for arg in (0, 1):
     for k, nm in names.items():
         cyc, n = buf[k * 2 + arg * 32], buf[k * 2 + 1 + arg * 32]

@@ -4,5 +4,6 @@ set -e
 cd "$(dirname "$0")"
 FLAGS="-O2 -g"
 OUT=libdeft4g_hostsim.so
+if [ "$1" = "waveheap" ]; then FLAGS="$FLAGS -DD4G_SIM_WAVE_HEAP"; OUT=libdeft4g_hostsim_wh.so; fi  # wave-wide tree builder in the emulator (slow)
 if [ "$1" = "san" ]; then FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined"; OUT=libdeft4g_hostsim_san.so; fi
 g++ -x c++ -std=c++17 $FLAGS -DD4G_HOSTSIM -include hipsim.h -fPIC -shared -o $OUT hipsim.cpp

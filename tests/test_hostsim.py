@@ -81,3 +81,19 @@ def test_long_blocks_decode_in_checkpoint_segments(sim):
     assert r["status"] == rc and r["saved_bits"] == saved and b.decoded(0) == raw
     assert b.output(0) == (want if rc == 0 else merged)
     b.close()
+
+
+def test_wave_wide_tree_builder_in_the_emulator():
+    """The GPU builds Huffman trees with a whole wave (priority queue in a register pair + LDS); the default
+    emulator build uses the one-lane builder, this variant runs the wave-wide code (slowly) on one small stream."""
+    os.environ["D4G_SIM_BLOCK"] = "64"
+    subprocess.check_call([os.path.join(ROOT, "tests", "hostsim", "build.sh"), "waveheap"])
+    import deft4j_amd as D
+    L = D.load_library(os.path.join(ROOT, "tests", "hostsim", "libdeft4g_hostsim_wh.so"))
+    D.init(0, lib=L)
+    a = synth.make_stream(1500, 3)
+    rc, want, saved, _, _ = O.optimise(a, False)
+    b = D.Batch([a], lib=L).run(False)
+    r = b.result(0)
+    assert r["status"] == rc and r["saved_bits"] == saved and b.output(0) == (want if rc == 0 else a)
+    b.close()
