@@ -71,6 +71,21 @@ D4G_DEV long long wave_sum_i64(long long v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// 32-bit wave sum: row scans and row broadcasts on the DPP path (six v_add_u32), no LDS crossbar trips
+D4G_DEV int wave_sum_i32(int v) {
+#ifdef D4G_HOSTSIM
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+#else
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
 D4G_DEV long long wave_min_i64(long long v) {
     for (int m = 32; m >= 1; m >>= 1) {
         long long o = __shfl_xor(v, m);
@@ -315,9 +330,11 @@ __device__ int d4g_tree_finish(TreeMem<H, I, MAXN>& m, int stride, int lane, int
 #ifdef D4G_HOSTSIM
 D4G_DEV int d4g_readlane(int v, int k) { return __shfl(v, k); }
 D4G_DEV int d4g_uniform(int v) { return __shfl(v, 0); }
+D4G_DEV void d4g_wave_sync() { (void)__shfl(0, 0); }   // the emulator's lanes are not in lock step: rendezvous
 #else
 D4G_DEV int d4g_readlane(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 D4G_DEV int d4g_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+D4G_DEV void d4g_wave_sync() { __builtin_amdgcn_wave_barrier(); }  // LDS accesses of one wave are already in order
 #endif
 
 struct D4GWaveHeap {

@@ -272,23 +272,24 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
                 atomicOr(&flags[1], 1u << bin);
             }
             int total = 0;
-            if (act && len <= D4G_LONG_TOKEN) {
+            const bool isLong = len > D4G_LONG_TOKEN;
+            if (act && !isLong) {
                 D4GLitWalk lw;
                 lw_start(lw, Uw, cur.y, len);
                 while (lw.rem > 0) lw_step(lw, Uw, lc);
                 total = lw.total;
             }
             // long back-references: the whole wave sums one record at a time (coalesced byte loads)
-            unsigned long long ml = __ballot(act && len > D4G_LONG_TOKEN);
+            unsigned long long ml = __ballot(act && isLong);
             while (ml) {
                 int srcLane = __ffsll((long long)ml) - 1;
                 ml &= ml - 1;
-                uint32_t o2 = __shfl(cur.y, srcLane);
-                int l2 = __shfl(len, srcLane);
+                uint32_t o2 = (uint32_t)d4g_readlane((int)cur.y, srcLane);
+                int l2 = d4g_readlane(len, srcLane);
                 const uint8_t* p2 = Ub + o2;
-                int tsum = 0;
-                for (int k = lane; k < l2; k += 64) tsum += lc[p2[k]];
-                tsum = (int)wave_sum_i64(tsum);
+                int part = 0;
+                for (int k = lane; k < l2; k += 64) part += lc[p2[k]];
+                int tsum = wave_sum_i32(part);
                 if (lane == srcLane) total = tsum;
             }
             if (act) {
@@ -353,6 +354,23 @@ __device__ void t0_build_cl_tree(D4GLds* L) {
     int err = d4g_build_tree(tm, 1, 0, 19, 7, [&](int i) { return (unsigned)L->clFreq[i]; },
                              [&](int v, int len) { S->clLen[v] = (uint8_t)len; });
     if (err) S->flags |= 0x100;
+}
+
+// the same by all lanes of wave 0
+__device__ void w0_build_cl_tree(D4GLds* L) {
+    D4GState* S = &L->st;
+#if !defined(D4G_HOSTSIM) || defined(D4G_SIM_WAVE_HEAP)
+    TreeMem<uint32_t, uint8_t, 20> tm;
+    tm.carve(L->treeCl, 1);
+    const int lane = threadIdx.x & 63;
+    if (lane < 19) S->clLen[lane] = 0;
+    int err = d4g_build_tree_wave<1>(tm, 19, 7, [&](int i) { return (unsigned)L->clFreq[i]; },
+                                     [&](int v, int len) { S->clLen[v] = (uint8_t)len; });
+    if (err && lane == 0) S->flags |= 0x100;
+#else
+    if ((threadIdx.x & 63) == 0) t0_build_cl_tree(L);
+#endif
+    d4g_wave_sync();
 }
 
 // removeTrailingHeaderCodes — DeflateBlockHuffman.java:366-370 (thread 0)
@@ -420,17 +438,17 @@ __device__ void wg_rewrite_header(D4GLds* L, int flags) {
             base += __shfl(incl, 63);
         }
         if (lane == 0) S->nPairs = base;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        S->sizeBits -= S->hdrBits;
-        t0_build_cl_tree(L);
-        S->nCl = 19;
-        long long hb = 5 + 5 + 4 + 19 * 3;
-        for (int s = 0; s < 19; s++) hb += (long long)L->clFreq[s] * (S->clLen[s] + (s >= 16 ? pair_extra_bits(s) : 0));
-        S->hdrBits = hb;
-        S->sizeBits += hb;
-        t0_remove_trailing_header_codes(S);
+        // code-length code (Huffman.ofRLEPacked, B/huffman/Huffman.java:117-134) and the header's size
+        w0_build_cl_tree(L);
+        int hbl = 0;
+        if (lane < 19) hbl = (int)L->clFreq[lane] * (S->clLen[lane] + (lane >= 16 ? pair_extra_bits(lane) : 0));
+        long long hb = 5 + 5 + 4 + 19 * 3 + wave_sum_i64(hbl);
+        if (lane == 0) {
+            S->sizeBits += hb - S->hdrBits;
+            S->hdrBits = hb;
+            S->nCl = 19;
+            t0_remove_trailing_header_codes(S);
+        }
     }
     __syncthreads();
 }
