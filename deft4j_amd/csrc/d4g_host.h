@@ -480,7 +480,7 @@ struct Batch {
 
     ~Batch() {
         rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
-        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dCpPool); rt_free(dReady); rt_free(dHeads);
+        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
@@ -515,11 +515,10 @@ struct Batch {
     }
 
     // ---- parse: header scan -> block probes -> chain -> emit -> pointer jumping ----
-    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits; i64 cpIndex; int nCp; i64 nRef; };
+    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits, nRef; };
     struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; };
     std::vector<PStream> ps;
     D4GStreamDesc* dStreams = nullptr;
-    D4GCpSet* dCpPool = nullptr;   // checkpoint sets of the scan candidates (parallel segment emit)
     uint32_t* dSrc = nullptr;
     int slotsAlloc = 0;
     double msParseKernels = 0;
@@ -566,8 +565,7 @@ struct Batch {
             // 2. speculative probes
             if (nc) {
                 D4GProbeOut* dPo = (D4GProbeOut*)rt_malloc((size_t)nc * sizeof(D4GProbeOut));
-                dCpPool = (D4GCpSet*)rt_malloc((size_t)nc * sizeof(D4GCpSet));
-                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, dPo, nc, dCpPool);
+                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, dPo, nc);
                 stats.kernel_launches++;
                 cands.resize(nc);
                 pout.resize(nc);
@@ -588,10 +586,10 @@ struct Batch {
         std::vector<char> done(n, 0);
         D4GProbeIn* dEx = (D4GProbeIn*)rt_malloc(n * sizeof(D4GProbeIn) + 16);
         D4GProbeOut* dExOut = (D4GProbeOut*)rt_malloc(n * sizeof(D4GProbeOut) + 16);
-        auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o, i64 cpIndex) {
+        auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o) {
             PStream& P = ps[i];
             if (o.status != 0 || o.needHist > upos[i]) { P.status = -1; done[i] = 1; return; }
-            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, o.nCp > 0 ? cpIndex : -1, o.nCp > 0 ? o.nCp : 0, (i64)o.nRef});
+            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, (i64)o.nRef});
             upos[i] += o.uLen;
             P.nTok += o.nTok;
             spos[i] += 3;  // DeflateStream.getSizeBits — :171-182
@@ -613,18 +611,18 @@ struct Batch {
                 while (!done[i]) {
                     auto& v = byStream[i];
                     auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(cur[i], -1));
-                    if (it != v.end() && it->first == cur[i]) accept(i, cur[i], pout[it->second], it->second);
+                    if (it != v.end() && it->first == cur[i]) accept(i, cur[i], pout[it->second]);
                     else { ex.push_back({(int32_t)i, 0, cur[i]}); exStream.push_back(i); break; }
                 }
             }
             if (ex.empty()) break;
             rt_h2d(dEx, ex.data(), ex.size() * sizeof(D4GProbeIn));
-            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GCpSet*)nullptr);
+            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size());
             stats.kernel_launches++;
             stats.exact_probes += (i64)ex.size();
             std::vector<D4GProbeOut> eo(ex.size());
             rt_d2h(eo.data(), dExOut, ex.size() * sizeof(D4GProbeOut));
-            for (size_t k = 0; k < ex.size(); k++) accept(exStream[k], ex[k].bitPos, eo[k], -1);
+            for (size_t k = 0; k < ex.size(); k++) accept(exStream[k], ex[k].bitPos, eo[k]);
         }
         rt_free(dEx); rt_free(dExOut);
         e1.record();
@@ -709,8 +707,6 @@ struct Batch {
                 em.uLen = pb.uLen;
                 em.stateIdx = -1;
                 em.sizeBits = pb.sizeBits;
-                em.cpIndex = pb.cpIndex;
-                em.nCp = pb.nCp;
                 em.refStart = hb.refStart;
                 if (pb.type != D4G_STORED) {
                     hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.refStart, hb.refCount, hb.uStart, hb.uLen, (hb.refCount + 63) / 64,
@@ -765,20 +761,8 @@ struct Batch {
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
             D4GParseOut po = {dTok, dU, dStates, dRefs, dTokRef};
-            RT_LAUNCH(k_emit_init, emits.size(), 64, dStreams, dEm, po, E.dErrors);
+            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors);
             stats.kernel_launches++;
-            std::vector<D4GEmitSeg> segs;
-            for (size_t e = 0; e < emits.size(); e++)
-                if (emits[e].type != D4G_STORED)
-                    for (int sgi = 0; sgi <= emits[e].nCp; sgi++) segs.push_back({(int32_t)e, sgi});
-            if (!segs.empty()) {
-                D4GEmitSeg* dSegs = (D4GEmitSeg*)rt_malloc(segs.size() * sizeof(D4GEmitSeg));
-                rt_h2d(dSegs, segs.data(), segs.size() * sizeof(D4GEmitSeg));
-                RT_LAUNCH(k_emit_segments, segs.size(), 64, dStreams, dEm, dSegs, dCpPool, po, E.dErrors);
-                stats.kernel_launches++;
-                rt_sync();
-                rt_free(dSegs);
-            }
             // 4. decoded bytes
             D4GTokRange* dRanges = (D4GTokRange*)rt_malloc(ranges.size() * sizeof(D4GTokRange));
             rt_h2d(dRanges, ranges.data(), ranges.size() * sizeof(D4GTokRange));

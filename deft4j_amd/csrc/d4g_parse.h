@@ -20,6 +20,8 @@
 // Decoding itself keeps the reference's semantics (LUT fast path; bit-serial canonical fallback
 // identical to Huffman.readSymbol, B/huffman/Huffman.java:170-197; reads past EOF fail).
 #pragma once
+#include <type_traits>
+
 #include "d4g_device.h"
 
 struct D4GStreamDesc {
@@ -42,15 +44,9 @@ struct D4GProbeOut {
     long long endBit;      // first bit after the block
     long long nTok, uLen, sizeBits;
     long long needHist;    // max over back-references of (distance - bytes produced so far in the block)
-    int32_t nCp;           // checkpoints recorded
     int32_t nRef;          // back-reference tokens in the block
+    int32_t pad;
 };
-// Probes leave up to 32 checkpoints per block (token boundaries with their bit position and running
-// token / byte counts) so that the emit pass can decode a block's segments in parallel.
-#define D4G_MAXCP 32
-struct D4GCheckpoint { long long bitPos; unsigned nTok; unsigned nU; unsigned nRef; unsigned pad; };
-struct D4GCpSet { int32_t n; int32_t pad; D4GCheckpoint cp[D4G_MAXCP]; };
-
 struct D4GEmitIn {
     int32_t stream;
     int32_t type;
@@ -60,21 +56,8 @@ struct D4GEmitIn {
     long long uLen;
     long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
     long long sizeBits;    // from the probe
-    long long cpIndex;     // index of the block's checkpoint set (-1: none, the block is one segment)
     long long refStart;    // absolute index of the block's first back-reference record
-    int32_t nCp;
-    int32_t pad;
 };
-struct D4GEmitSeg { int32_t emit; int32_t seg; };  // segment `seg` (0..nCp) of emit job `emit`
-// how d4g_parse_block runs
-struct D4GSegCtl {
-    int mode;              // 0 whole block; 1 header only (write the block's state with an empty histogram); 2 one segment
-    long long startBit;    // mode 2, seg > 0: first bit of the segment (a token boundary)
-    unsigned startTok, startU, startRef;
-    long long endBit;      // mode 2: stop at this token boundary (-1: run to EOB)
-    D4GCpSet* cpOut;       // mode 0, probe: where to leave the checkpoints (may be null)
-};
-
 #define D4G_LUT_BITS 10
 #define D4G_INCH 8192
 
@@ -91,7 +74,6 @@ struct D4GParseLds {
     D4GState st;
     D4GDecTab lit, dist, cl;
     alignas(16) uint8_t inbuf[D4G_INCH + 16];
-    D4GCpSet cps;          // probe: checkpoints recorded for the block
 };
 
 // Bit reader owned by lane 0 (B/io/BitInputStream.java:59-82: LSB-first).
@@ -139,6 +121,17 @@ struct D4GBitReader {
     __device__ void skip(int n) { buf >>= n; cnt -= n; posRel += n; }
     __device__ bool near_end() const { return rel + 1024 > D4G_INCH; }
 };
+
+#define D4G_CHUNK_BITS 256   // bits per lane and pass of the wave-wide token decoder
+// 64 bits of the staged input starting at bit `posRel` (any lane, any position inside the staged chunk)
+__device__ __forceinline__ uint64_t d4g_peek64(const uint8_t* inbuf, int posRel) {
+    int a = (posRel >> 3) & ~3;
+    int sh = posRel - a * 8;   // 0..31
+    const uint32_t* w = (const uint32_t*)(inbuf + a);
+    uint64_t lo = ((uint64_t)w[1] << 32) | w[0];
+    uint64_t hi = w[2];
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
 
 // Huffman.buildCodes (B/huffman/Huffman.java:35-64) + decoder tables.  Lane 0 prepares the
 // canonical structure, all lanes fill the LUT.
@@ -280,7 +273,7 @@ struct D4GParseOut {
 
 template <bool EMIT>
 __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long long bitPos, int strict, D4GProbeOut& po,
-                                const D4GEmitIn* em, const D4GParseOut& out, const D4GSegCtl& sc) {
+                                const D4GEmitIn* em, const D4GParseOut& out) {
     __shared__ D4GParseLds L;
     int lane = threadIdx.x & 63;
     D4GBitReader br;
@@ -288,7 +281,6 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     br.nbits = sd.len * 8;
     br.rel = 0; br.posRel = 0; br.limitRel = 0; br.buf = 0; br.cnt = 0;
     D4GState* S = &L.st;
-    int segEndRel = 0x7fffffff;  // segment end relative to the staged chunk (mode 2)
     auto stage = [&](long long bitpos) {
         long long base = (bitpos >> 3) & ~15LL;
         if (base > sd.len) base = sd.len & ~15LL;
@@ -297,10 +289,8 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         __syncthreads();
         br.inBase = base;
         if (lane == 0) br.reset_to(L.inbuf, bitpos);
-        long long e = sc.endBit - base * 8;
-        segEndRel = (sc.mode == 2 && sc.endBit >= 0) ? (e > 0x3fffffff ? 0x3fffffff : (int)e) : 0x7fffffff;
     };
-    po.nCp = 0; po.nRef = 0;
+    po.nRef = 0; po.pad = 0;
     po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
     stage(bitPos);
     long long pk = 0;
@@ -423,21 +413,6 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         r = __shfl(r, 0);
         if (r < 0) return;
     }
-    if (EMIT && sc.mode == 1) {
-        // header only: the block's state with an empty histogram (the segment waves add their counts)
-        if (lane == 0) {
-            if (btype == 1) { S->litLen[286] = 0; S->litLen[287] = 0; }
-            S->sizeBits = em->sizeBits;
-            S->litlenBits = em->sizeBits - S->hdrBits;
-            S->valid = 1;
-            S->maskSlot = 0;
-        }
-        __syncthreads();
-        D4GState* g = out.states + em->stateIdx;
-        for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
-        po.status = 0;
-        return;
-    }
     d4g_build_decoder(&L.lit, S->litLen, btype == 1 ? 288 : S->nLit);
     d4g_build_decoder(&L.dist, S->distLen, btype == 1 ? 30 : S->nDist);
     if (btype == 1 && lane == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
@@ -447,117 +422,129 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         bool good = L.lit.complete && S->litLen[256] > 0 && (L.dist.complete || L.dist.nCodes <= 1);
         if (!good) return;
     }
-    // ---- decodeStream — DeflateBlockHuffman.java:778-890: lane 0 decodes, the wave refills the input chunk ----
-    // 32-bit counters inside the loop: a block's tokens, bytes and bits fit comfortably
-    unsigned litlenBits = 0, nTok = 0, nU = 0, nRef = 0;
+    // ---- decodeStream — DeflateBlockHuffman.java:778-890, by the whole wave ----
+    // The block's bits are cut into chunks of D4G_CHUNK_BITS; 64 chunks make a batch.  Lane i decodes chunk i
+    // from a start position: lane 0 from the known token boundary, the others from a guess (their chunk's
+    // first bit).  A decoder started off a token boundary usually falls into step with the true token
+    // sequence after a few codes, so its exit position (first token boundary past the chunk's end) is
+    // usually right.  Each pass hands every lane its left neighbour's exit as the new start and re-decodes the
+    // chunks whose start changed; when a pass changes nothing, start(i+1) == exit(i) for all i and start(0) is
+    // true, so every start is a true token boundary — the check is exact, at worst after 64 passes.
+    const long long tokensStart = __shfl(br.pos(), 0);
+    long long s0 = tokensStart;   // true token boundary where the batch begins
+    long long G = s0;             // grid origin of the batch: chunk i covers [G + i*C, G + (i+1)*C)
+    unsigned nTok = 0, nU = 0, nRef = 0, litlenBits = 0;
     int needHist = 0;
     uint2* tokOut = EMIT ? out.tok + em->tokStart : nullptr;
     uint2* refOut = EMIT ? out.refs + em->refStart : nullptr;
     uint32_t* tokRefOut = EMIT ? out.tokRef + em->tokStart : nullptr;
     const uint32_t refBase32 = EMIT ? (uint32_t)em->refStart : 0u;
     const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
-    if (EMIT && sc.mode == 2) {
-        if (sc.startBit >= 0) stage(sc.startBit);   // segment > 0 starts at a checkpoint; segment 0 right after the header
-        nTok = sc.startTok;
-        nU = sc.startU;
-        nRef = sc.startRef;
-    }
-    // probe: checkpoints every `cpSpacing` tokens; when the set is full every other one is dropped
-    unsigned cpSpacing = 1024, nextCp = 1024;
-    int nCp = 0;
-    const bool recordCp = !EMIT && sc.cpOut != nullptr;
-    int done = 0;  // 1 EOB, 3 segment end, -1 failure
-    while (true) {
-        long long code = 0;
-        if (lane == 0) {
-            const bool chunkCoversEnd = br.inBase + D4G_INCH >= sd.len + 16;
-            while (true) {
-                if (br.near_end() && !chunkCoversEnd) { code = 2; break; }  // refill needed
-                if (EMIT && br.posRel >= segEndRel) { code = br.posRel == segEndRel ? 3 : -1; break; }
-                if (recordCp && nTok == nextCp) {
-                    nextCp += 1024;
-                    if ((nTok & (cpSpacing - 1)) == 0) {
-                        if (nCp == D4G_MAXCP) {  // keep the checkpoints at multiples of twice the spacing
-                            for (int i = 0; i < D4G_MAXCP / 2; i++) L.cps.cp[i] = L.cps.cp[2 * i + 1];
-                            nCp = D4G_MAXCP / 2;
-                            cpSpacing *= 2;
-                        }
-                        if ((nTok & (cpSpacing - 1)) == 0) {
-                            L.cps.cp[nCp].bitPos = br.pos();
-                            L.cps.cp[nCp].nTok = nTok;
-                            L.cps.cp[nCp].nU = nU;
-                            L.cps.cp[nCp].nRef = nRef;
-                            L.cps.cp[nCp].pad = 0;
-                            nCp++;
-                        }
-                    }
+    long long endBit = 0;
+    constexpr int C = D4G_CHUNK_BITS;
+    // one chunk: WRITE = false counts, WRITE = true also stores the tokens (the lane's output offsets are known then)
+    auto decode_chunk = [&](auto writeTag, int start, int endc, int limRel, unsigned tokAt, unsigned uAt, unsigned refAt, int& exitp,
+                            unsigned& n, unsigned& u, unsigned& r, unsigned& lb, int& need, int& fl) D4G_LAMBDA_INLINE {
+        constexpr bool WRITE = decltype(writeTag)::value;
+        int pos = start;
+        n = 0; u = 0; r = 0; lb = 0; need = -0x40000000; fl = 0;
+        while (pos < endc) {
+            uint64_t bits = d4g_peek64(L.inbuf, pos);
+            int avail = limRel - pos;
+            int cl = 0, sym;
+            D4G_DECODE(&L.lit, bits, avail, sym, cl);
+            if (sym < 0 || sym > 285) { fl = 2; break; }
+            int used = cl;
+            if (sym <= 256) {
+                if (WRITE) {
+                    atomicAdd(&S->hist[sym], 1u);
+                    tokOut[tokAt + n] = make_uint2((uint32_t)sym, uStart32 + uAt + u);
                 }
-                br.fill(L.inbuf);
-                uint64_t bits = br.buf;
-                int avail = br.avail();
-                int cl = 0, val = 0, dist = 0, edge = 0, used = 0;
-                int sym;
-                D4G_DECODE(&L.lit, bits, avail, sym, cl);
-                if (sym < 0 || sym > 285) { code = -1; break; }
-                if (sym <= 256) { val = sym; used = cl; if (EMIT) S->hist[sym]++; br.skip(used); }
-                else {
-                    int eb = d4g_lsym_ebits(sym);
-                    int len = d4g_lsym_base(sym);
-                    used = cl + eb;
-                    if (used > avail) { code = -1; break; }
-                    len += (int)((bits >> cl) & ((1u << eb) - 1));
-                    edge = (len == 258 && sym == 284);
-                    br.skip(used);
-                    br.fill(L.inbuf);           // second refill: distance code + extra bits (<= 28 bits)
-                    bits = br.buf;
-                    avail = br.avail();
-                    int dcl = 0, ds;
-                    D4G_DECODE(&L.dist, bits, avail, ds, dcl);
-                    if (ds < 0 || ds > 29) { code = -1; break; }
-                    int deb = d4g_dsym_ebits(ds);
-                    if (dcl + deb > avail) { code = -1; break; }
-                    dist = d4g_dsym_base(ds) + (int)((bits >> dcl) & ((1u << deb) - 1));
-                    br.skip(dcl + deb);
-                    used += dcl + deb;
-                    if (nU < 32768u && dist - (int)nU > needHist) needHist = dist - (int)nU;  // only the block's first 32 KiB can reach back past its start
-                    if (EMIT) {
-                        S->hist[sym]++; S->hist[D4G_NLIT + ds]++;
-                        refOut[nRef] = make_uint2(d4g_ref_pack(len, sym, ds, eb + deb), uStart32 + nU);
-                        tokRefOut[nTok] = refBase32 + nRef;
-                    }
-                    nRef++;
-                    val = len;
+                n++;
+                lb += (unsigned)used;
+                pos += used;
+                if (sym == 256) { fl = 1; break; }
+                u++;
+            } else {
+                int eb = d4g_lsym_ebits(sym);
+                int len = d4g_lsym_base(sym) + (int)((bits >> cl) & ((1u << eb) - 1));
+                used += eb;
+                int edge = (len == 258 && sym == 284);
+                int dcl = 0, ds;
+                D4G_DECODE(&L.dist, bits >> used, avail - used, ds, dcl);
+                if (ds < 0 || ds > 29) { fl = 2; break; }
+                int deb = d4g_dsym_ebits(ds);
+                int dist = d4g_dsym_base(ds) + (int)((bits >> (used + dcl)) & ((1u << deb) - 1));
+                used += dcl + deb;
+                if (used > avail) { fl = 2; break; }
+                if (dist - (int)u > need) need = dist - (int)u;
+                if (WRITE) {
+                    atomicAdd(&S->hist[sym], 1u);
+                    atomicAdd(&S->hist[D4G_NLIT + ds], 1u);
+                    tokOut[tokAt + n] = make_uint2((uint32_t)len | ((uint32_t)edge << 15) | ((uint32_t)dist << 16), uStart32 + uAt + u);
+                    refOut[refAt + r] = make_uint2(d4g_ref_pack(len, sym, ds, eb + deb), uStart32 + uAt + u);
+                    tokRefOut[tokAt + n] = refBase32 + refAt + r;
                 }
-                litlenBits += (unsigned)used;
-                if (EMIT) tokOut[nTok] = make_uint2((uint32_t)val | ((uint32_t)edge << 15) | ((uint32_t)dist << 16), uStart32 + nU);
-                nTok++;
-                if (sym == 256) { code = 1; break; }
-                nU += dist ? (unsigned)val : 1u;
+                n++; r++;
+                lb += (unsigned)used;
+                pos += used;
+                u += (unsigned)len;
             }
         }
-        code = __shfl(code, 0);
-        if (code == 2) {
-            long long bitpos = __shfl(br.pos(), 0);
-            stage(bitpos);
-            continue;
+        exitp = pos;
+    };
+    while (true) {
+        // the staged input must cover the batch: 64 chunks, one token of overshoot, the 12-byte window of a peek
+        {
+            long long baseBits = br.inBase * 8;
+            bool covers = s0 >= baseBits && (G - baseBits) + 64LL * C + 64 + 96 <= (long long)(D4G_INCH + 16) * 8;
+            if (!covers) stage(s0);   // wave-uniform decision
         }
-        done = (int)code;
-        break;
+        const long long baseBits = br.inBase * 8;
+        const int Grel = (int)(G - baseBits), s0rel = (int)(s0 - baseBits);
+        long long lim = br.nbits - baseBits;
+        const int limRel = lim > 0x3fffffff ? 0x3fffffff : (int)lim;
+        int start = lane == 0 ? s0rel : Grel + lane * C;
+        const int endc = Grel + (lane + 1) * C;
+        int exitp = start, need = 0, fl = 0;
+        unsigned n = 0, u = 0, r = 0, lb = 0;
+        bool dirty = true;
+        for (int pass = 0; pass < 66; pass++) {
+            if (dirty) decode_chunk(std::false_type{}, start, endc, limRel, 0u, 0u, 0u, exitp, n, u, r, lb, need, fl);
+            int pe = __shfl_up(exitp, 1), pfl = __shfl_up(fl, 1);
+            dirty = lane > 0 && pfl == 0 && pe != start;
+            if (dirty) start = pe;
+            if (!__ballot(dirty)) break;
+        }
+        // the block ends (or fails) in the first lane that stopped early; lanes up to it hold true tokens
+        unsigned long long tm = __ballot(fl != 0);
+        const int f = tm ? __ffsll((long long)tm) - 1 : 64;
+        const bool valid = lane <= f;
+        if (f < 64 && __shfl(fl, f) == 2) return;   // invalid code or out of input: the block does not parse
+        unsigned pn = valid ? n : 0u, pu = valid ? u : 0u, pr = valid ? r : 0u, plb = valid ? lb : 0u;
+        unsigned sn = pn, su = pu, sr = pr;   // inclusive scans
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned a = __shfl_up(sn, d), b = __shfl_up(su, d), c2 = __shfl_up(sr, d);
+            if (lane >= d) { sn += a; su += b; sr += c2; }
+        }
+        int nd = valid && r ? need - (int)(nU + (su - pu)) : -0x40000000;
+        nd = wave_max_i32(nd);
+        if (nd > needHist) needHist = nd;
+        if (EMIT && valid) {
+            int e2, need2, fl2;
+            unsigned n2, u2, r2, lb2;
+            decode_chunk(std::true_type{}, start, endc, limRel, nTok + (sn - pn), nU + (su - pu), nRef + (sr - pr), e2, n2, u2, r2, lb2, need2,
+                         fl2);
+        }
+        nTok += __shfl(sn, 63);
+        nU += __shfl(su, 63);
+        nRef += __shfl(sr, 63);
+        litlenBits += (unsigned)wave_sum_i32((int)plb);
+        if (f < 64) { endBit = baseBits + __shfl(exitp, f); break; }
+        s0 = baseBits + __shfl(exitp, 63);
+        G += 64LL * C;
     }
-    if (done < 0) return;
-    if (EMIT && sc.mode == 2) {
-        // a segment adds its symbol counts to the block's histogram and reports where it stopped
-        __syncthreads();
-        uint32_t* gh = out.states[em->stateIdx].hist;
-        for (int i = lane; i < D4G_HIST; i += 64)
-            if (S->hist[i]) atomicAdd(&gh[i], S->hist[i]);
-        po.status = (done == 3 && sc.endBit < 0) ? -1 : 0;   // the last segment must end at the EOB
-        po.endBit = __shfl(br.pos(), 0);
-        po.nTok = (long long)__shfl(nTok, 0);
-        po.uLen = (long long)__shfl(nU, 0);
-        if (done == 1 && sc.endBit >= 0) po.status = -1;      // an inner segment must not see the EOB
-        return;
-    }
+    __syncthreads();
     if (lane == 0) {
         S->litlenBits = (long long)litlenBits;
         S->sizeBits = S->hdrBits + (long long)litlenBits;
@@ -565,64 +552,35 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         S->maskSlot = 0;
     }
     __syncthreads();
-    if (recordCp) {
-        int n = __shfl(nCp, 0);
-        po.nCp = n;
-        if (lane == 0) L.cps.n = n;
-        __syncthreads();
-        for (int i = lane; i < (int)(sizeof(D4GCpSet) / 4); i += 64) ((uint32_t*)sc.cpOut)[i] = ((uint32_t*)&L.cps)[i];
-    }
     po.status = 0;
-    po.endBit = __shfl(br.pos(), 0);
-    po.nTok = (long long)__shfl(nTok, 0);
-    po.uLen = (long long)__shfl(nU, 0);
+    po.endBit = endBit;
+    po.nTok = (long long)nTok;
+    po.uLen = (long long)nU;
     po.sizeBits = S->sizeBits;
-    po.needHist = (long long)__shfl(needHist, 0);
-    po.nRef = (int32_t)__shfl(nRef, 0);
+    po.needHist = (long long)needHist;
+    po.nRef = (int32_t)nRef;
     if (EMIT) {
         D4GState* g = out.states + em->stateIdx;
         for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
     }
 }
 
-__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
-                                                     D4GCpSet* cpPool) {
+__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n) {
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
     D4GParseOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    D4GSegCtl sc = {0, -1, 0u, 0u, 0u, -1, cpPool ? cpPool + blockIdx.x : nullptr};
-    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none, sc);
+    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
     if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
 }
 
-// Emit, step 1: one wave per block re-reads the header and writes the block's initial state (stored blocks:
-// their bytes).  Step 2: one wave per segment decodes its tokens.
-__global__ void __launch_bounds__(64) k_emit_init(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
+// Emit: one wave per block decodes it again, now writing tokens, back-reference records, the block's
+// initial state (stored blocks: their bytes).
+__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
     const D4GEmitIn em = in[blockIdx.x];
     D4GProbeOut po;
-    D4GSegCtl sc = {1, -1, 0u, 0u, 0u, -1, nullptr};
-    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, sc);
-    if ((threadIdx.x & 63) == 0 && (po.status != 0 || (em.type == D4G_STORED && po.uLen != em.uLen))) atomicAdd(errors, 1);
-}
-
-__global__ void __launch_bounds__(64) k_emit_segments(const D4GStreamDesc* streams, const D4GEmitIn* in, const D4GEmitSeg* segs,
-                                                      const D4GCpSet* cpPool, D4GParseOut out, int32_t* errors) {
-    const D4GEmitSeg sg = segs[blockIdx.x];
-    const D4GEmitIn em = in[sg.emit];
-    D4GSegCtl sc = {2, -1, 0u, 0u, 0u, -1, nullptr};
-    if (em.cpIndex >= 0) {
-        const D4GCpSet* cs = cpPool + em.cpIndex;
-        if (sg.seg > 0) { sc.startBit = cs->cp[sg.seg - 1].bitPos; sc.startTok = cs->cp[sg.seg - 1].nTok; sc.startU = cs->cp[sg.seg - 1].nU; sc.startRef = cs->cp[sg.seg - 1].nRef; }
-        if (sg.seg < em.nCp) sc.endBit = cs->cp[sg.seg].bitPos;
-    }
-    D4GProbeOut po;
-    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, sc);
-    if ((threadIdx.x & 63) == 0) {
-        bool bad = po.status != 0;
-        if (!bad && sc.endBit < 0 && po.uLen != em.uLen) bad = true;   // the last segment ends the block
-        if (bad) atomicAdd(errors, 1);
-    }
+    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out);
+    if ((threadIdx.x & 63) == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
 }
 
 // ---------------------------------------------------------------------------------------
