@@ -940,7 +940,8 @@ struct D4GHdrLds {
     alignas(16) uint8_t lens[D4G_NLIT + D4G_NDIST];
     uint8_t runV[D4G_MAXPAIRS];
     uint16_t runL[D4G_MAXPAIRS];
-    int nRuns;
+    int nRuns;              // runs whose packing depends on the flags (the others are summed in baseFreq)
+    uint32_t baseFreq[20];  // code-length symbols contributed by the runs every candidate packs as plain literals
     alignas(16) unsigned char tree[TreeMem<uint32_t, uint8_t, 20>::bytes(64)];
     uint16_t freq[19 * 64];
     uint8_t cl0[19 * 64];
@@ -954,7 +955,7 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
 #define C0(s) H->cl0[(s) * 64 + lane]
 #define C1(s) H->cl1[(s) * 64 + lane]
     int nRuns = H->nRuns;
-    for (int s = 0; s < 19; s++) { FQ(s) = 0; C0(s) = 0; C1(s) = 0; }
+    for (int s = 0; s < 19; s++) { FQ(s) = (uint16_t)H->baseFreq[s]; C0(s) = 0; C1(s) = 0; }
     // rewriteHeader(flags): symbol counts of the packed lengths
     for (int r = 0; r < nRuns; r++)
         d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int, int) { FQ(sym)++; });
@@ -966,7 +967,7 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
     bool useC1 = false;
     if (prune) {
         // recodeHeaderToLessRLEMatches: expand runs that are not shorter than literals, then re-derive the code
-        for (int s = 0; s < 19; s++) FQ(s) = 0;
+        for (int s = 0; s < 19; s++) FQ(s) = (uint16_t)H->baseFreq[s];
         for (int r = 0; r < nRuns; r++)
             d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int run, int value) {
                 if (sym >= 16 && pair_replace_gain(sym, run, value, true, [&](int s) { return (int)C0(s); }) >= 0) FQ(value) += run;
@@ -1021,10 +1022,51 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? H.lens[i] : H.lens[D4G_NLIT + i - nLit];
     __syncthreads();
     long long baseLitlenBits = (long long)ld_sc1((const uint64_t*)&base->litlenBits);
-    if (lane == 0) {
-        int nr = 0;
-        d4g_for_runs(n, [&](int i) { return (int)comb[i]; }, [&](int v, int r) { H.runV[nr] = (uint8_t)v; H.runL[nr] = (uint16_t)r; nr++; });
-        H.nRuns = nr;
+    // Runs of the combined code lengths, found with ballots.  HuffmanTable.pack turns a run of up to three equal
+    // non-zero lengths (up to two zeros) into plain literals whatever the flags: those only add to the symbol
+    // counts, once for all 56 candidates.  The other runs are listed for the candidates' own packing (their
+    // order does not matter: candidates only count symbols and sum savings).
+    if (lane < 20) H.baseFreq[lane] = 0;
+    __syncthreads();
+    {
+        constexpr int NCH = (D4G_NLIT + D4G_NDIST) / 64;
+        unsigned long long sm[NCH];
+        int v[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            int i = ch * 64 + lane;
+            v[ch] = i < n ? (int)comb[i] : -1;
+            int pv = (i > 0 && i < n) ? (int)comb[i - 1] : -2;
+            sm[ch] = __ballot(i < n && v[ch] != pv);
+        }
+        int ncx = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            int i = ch * 64 + lane;
+            bool start = (sm[ch] >> lane) & 1;
+            int run = 0;
+            if (start) {
+                int nx = -1;
+                unsigned long long m = lane == 63 ? 0ULL : (sm[ch] >> (lane + 1));
+                if (m) nx = i + __ffsll((long long)m);
+#pragma unroll
+                for (int c2 = ch + 1; c2 < NCH; c2++)
+                    if (nx < 0 && sm[c2]) nx = c2 * 64 + __ffsll((long long)sm[c2]) - 1;
+                if (nx < 0) nx = n;
+                run = nx - i;
+            }
+            bool simple = start && (v[ch] != 0 ? run <= 3 : run <= 2);
+            bool cx = start && !simple;
+            if (simple) atomicAdd(&H.baseFreq[v[ch]], (unsigned)run);
+            unsigned long long cm = __ballot(cx);
+            if (cx) {
+                int idx = ncx + __popcll(cm & ((1ULL << lane) - 1));
+                H.runV[idx] = (uint8_t)v[ch];
+                H.runL[idx] = (uint16_t)run;
+            }
+            ncx += __popcll(cm);
+        }
+        if (lane == 0) H.nRuns = ncx;
     }
     __syncthreads();
     long long key = D4G_KEY_NONE;
