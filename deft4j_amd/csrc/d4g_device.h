@@ -141,7 +141,9 @@ D4G_DEV int wg_max_i32(int v, long long* red) {
 // Heap entries carry their weight (weight << IDBITS | node id), so one LDS read per heap slot decides a
 // sift step; node weights are never looked up separately.  H = heap entry type (u64 for the
 // literal/length and distance trees, u32 for the 19-symbol code-length tree).
-template <typename H, typename I, int MAXN>
+// IDB = bits of a heap entry that hold the node id; OVERLAY = firstAt / depth reuse the heap's memory (the
+// queue is empty by the time depths are computed) — the 64-trees-per-wave header search uses both to stay small.
+template <typename H, typename I, int MAXN, int IDB_ = 8 * (int)sizeof(I), bool OVERLAY = false>
 struct TreeMem {
     H* heap;     // [MAXN+1]  the priority queue
     I* left;     // [MAXN]    children of internal node id live at index id - nl
@@ -152,9 +154,10 @@ struct TreeMem {
     I* depth;    // [MAXN]    depth of each leaf
     static constexpr int NONE = (1 << (8 * sizeof(I) - 1)) - 1;
     static constexpr int SIDE = 1 << (8 * sizeof(I) - 1);
-    static constexpr int IDBITS = 8 * sizeof(I);
+    static constexpr int IDBITS = IDB_;
+    static_assert(!OVERLAY || sizeof(H) * (MAXN + 1) >= sizeof(I) * (2 * MAXN + 1), "heap too small to hold firstAt + depth");
     static constexpr size_t bytes(int lanes) {
-        return (size_t)lanes * (sizeof(H) * (MAXN + 1) + sizeof(I) * (MAXN * 2 + 2 * MAXN + MAXN + (MAXN + 1) + MAXN));
+        return (size_t)lanes * (sizeof(H) * (MAXN + 1) + sizeof(I) * (MAXN * 2 + 2 * MAXN + MAXN + (OVERLAY ? 0 : (MAXN + 1) + MAXN)));
     }
     __device__ void carve(unsigned char* base, int lanes) {
         heap = (H*)base; base += sizeof(H) * (MAXN + 1) * lanes;
@@ -162,23 +165,28 @@ struct TreeMem {
         right = (I*)base; base += sizeof(I) * MAXN * lanes;
         parent = (I*)base; base += sizeof(I) * 2 * MAXN * lanes;
         value = (I*)base; base += sizeof(I) * MAXN * lanes;
-        firstAt = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
-        depth = (I*)base;
+        if (OVERLAY) {
+            firstAt = (I*)heap;
+            depth = firstAt + (MAXN + 1) * lanes;
+        } else {
+            firstAt = (I*)base; base += sizeof(I) * (MAXN + 1) * lanes;
+            depth = (I*)base;
+        }
     }
 };
 
-template <typename H, typename I, int MAXN, typename OutFn>
-__device__ int d4g_tree_finish(TreeMem<H, I, MAXN>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
+template <typename H, typename I, int MAXN, int IDB_, bool OVL, typename OutFn>
+__device__ int d4g_tree_finish(TreeMem<H, I, MAXN, IDB_, OVL>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
                                OutFn outLen);
 
 // Returns 0 on success, 1 if the limiter could not rebalance (the reference throws there).
 // freq(i) reads symbol i's frequency; outLen(i, len) receives each symbol's code length.
-template <typename H, typename I, int MAXN, typename FreqFn, typename OutFn>
-__device__ int d4g_build_tree(TreeMem<H, I, MAXN>& m, int stride, int lane, int numSymbols, int limit, FreqFn freq,
+template <typename H, typename I, int MAXN, int IDB_, bool OVL, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree(TreeMem<H, I, MAXN, IDB_, OVL>& m, int stride, int lane, int numSymbols, int limit, FreqFn freq,
                               OutFn outLen) {
-    const int NONE = TreeMem<H, I, MAXN>::NONE;
-    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
-    const int IDB = TreeMem<H, I, MAXN>::IDBITS;
+    const int NONE = TreeMem<H, I, MAXN, IDB_, OVL>::NONE;
+    const int SIDE = TreeMem<H, I, MAXN, IDB_, OVL>::SIDE;
+    const int IDB = TreeMem<H, I, MAXN, IDB_, OVL>::IDBITS;
     const H IDMASK = ((H)1 << IDB) - 1;
 #define TM(arr, i) m.arr[(i) * stride + lane]
     int nl = 0, hs = 0;
@@ -255,11 +263,11 @@ __device__ int d4g_build_tree(TreeMem<H, I, MAXN>& m, int stride, int lane, int 
 
 // Second half of the builder: depths by DFS (traverse :134-158), the depth limiter (:75-127) and the
 // lengths (getTable :164-192) of a tree whose nodes are already in m.left / right / parent / value.
-template <typename H, typename I, int MAXN, typename OutFn>
-__device__ int d4g_tree_finish(TreeMem<H, I, MAXN>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
+template <typename H, typename I, int MAXN, int IDB_, bool OVL, typename OutFn>
+__device__ int d4g_tree_finish(TreeMem<H, I, MAXN, IDB_, OVL>& m, int stride, int lane, int nl, int root, int numSymbols, int limit,
                                OutFn outLen) {
-    const int NONE = TreeMem<H, I, MAXN>::NONE;
-    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
+    const int NONE = TreeMem<H, I, MAXN, IDB_, OVL>::NONE;
+    const int SIDE = TreeMem<H, I, MAXN, IDB_, OVL>::SIDE;
 #define TM(arr, i) m.arr[(i) * stride + lane]
     int maxDepth = 0;
     // traverse — DFS, left before right; records each leaf's depth and the first leaf per depth
@@ -356,9 +364,9 @@ struct D4GWaveHeap {
 };
 
 // All 64 lanes of one wave call this with the same arguments.  NREG = ceil(MAXN / 64).
-template <int NREG, typename H, typename I, int MAXN, typename FreqFn, typename OutFn>
-__device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN>& m, int numSymbols, int limit, FreqFn freq, OutFn outLen) {
-    const int SIDE = TreeMem<H, I, MAXN>::SIDE;
+template <int NREG, typename H, typename I, int MAXN, int IDB_, bool OVL, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSymbols, int limit, FreqFn freq, OutFn outLen) {
+    const int SIDE = TreeMem<H, I, MAXN, IDB_, OVL>::SIDE;
     const int lane = threadIdx.x & 63;
     numSymbols = d4g_uniform(numSymbols);  // tell the compiler what is wave-uniform: the queue code then runs on the scalar unit
     limit = d4g_uniform(limit);
@@ -529,6 +537,52 @@ __device__ void d4g_pack_run(int v, int r, int flags, Emit emit) {
     while (r > 0) { emit(v, 0, v); r--; }
 }
 
+// The same packing summarised in closed form (no loops): rep(sym, run, value, count) once per distinct
+// repeat pair (sym 16 / 17 / 18) the run produces, with its multiplicity, and lit(count) for the plain
+// code lengths `v` it leaves.  For callers that only count symbols or sum per-pair gains.
+template <typename Rep, typename Lit>
+__device__ void d4g_pack_kinds(int v, int r, int flags, Rep rep, Lit lit) {
+    if (v == 0) {
+        if (!(flags & F_NOZREP2)) {
+            int a = r / 138;
+            if (a) { rep(18, 138, 0, a); r -= a * 138; }
+            if (r >= 11) { rep(18, r, 0, 1); r = 0; }
+        }
+        if (!(flags & F_NOZREP)) {
+            int b = r / 10;
+            if (b) { rep(17, 10, 0, b); r -= b * 10; }
+            if (r >= 3) { rep(17, r, 0, 1); r = 0; }
+        }
+    }
+    int lits = 0;
+    if (!(flags & F_NOREP) && r > 0 && (!(flags & F_NOREPZEROS) || v != 0)) {
+        lits = 1;
+        r--;
+        // the j == 6 phase takes sixes until it meets the 8 / 7 special cases (when enabled) or fewer than six are left
+        const bool s8 = (flags & F_OHH) && (flags & F_USE8), s7 = (flags & F_OHH) && (flags & F_USE7);
+        if (s8 && r >= 8 && r % 6 == 2) {
+            int q = (r - 8) / 6;
+            if (q) rep(16, 6, v, q);
+            if (flags & F_ALT8) { rep(16, 5, v, 1); rep(16, 3, v, 1); }
+            else rep(16, 4, v, 2);
+            r = 0;
+        } else if (s7 && r >= 7 && r % 6 == 1) {
+            int q = (r - 7) / 6;
+            if (q) rep(16, 6, v, q);
+            rep(16, 4, v, 1);
+            rep(16, 3, v, 1);
+            r = 0;
+        } else {
+            int q = r / 6;
+            if (q) rep(16, 6, v, q);
+            r -= q * 6;
+            if (r >= 3) { rep(16, r, v, 1); r = 0; }   // one pair of 5, 4 or 3
+        }
+    }
+    lits += r;
+    if (lits) lit(lits);
+}
+
 // Runs of the concatenated code lengths (lit then dist; runs may span the boundary — A.4).
 // len(i) reads combined length i.  Calls body(value, runLength) per run.
 template <typename LenFn, typename Body>
@@ -567,6 +621,15 @@ D4G_DEV int pair_replace_gain(int sym, int run, int value, bool prune, ClFn cl) 
     int b = cl(value);
     if (b < 1) return -1;
     int total = run * b;
+    if (prune ? total > checkSize : total >= checkSize) return -1;
+    return checkSize - total;
+}
+
+// the same with the two code lengths already at hand (lsym = bits of the repeat symbol, lval = bits of the repeated value)
+D4G_DEV int pair_gain_bits(int sym, int run, int lsym, int lval, bool prune) {
+    int checkSize = lsym + pair_extra_bits(sym);
+    if (lval < 1) return -1;
+    int total = run * lval;
     if (prune ? total > checkSize : total >= checkSize) return -1;
     return checkSize - total;
 }

@@ -22,6 +22,16 @@ D4G_DEV void st_sc1(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC
 D4G_DEV int ld_state_i32(const int32_t* p) { return (int)ld_sc1((const uint32_t*)p); }
 
 
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+// profile builds: a clock read that is not overtaken by (and does not overtake) outstanding LDS / memory operations
+D4G_DEV long long d4g_clock_drained() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    long long t = clock64();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+#endif
+
 struct D4GCtx {
     const uint2* tok;         // {token word, decoded-byte offset}
     const uint2* refs;        // back-reference records {packed symbols/length, decoded-byte offset}
@@ -936,20 +946,25 @@ __global__ void __launch_bounds__(256) k_persist_state_ops(D4GCtx c, D4GQueue q)
 // Pairs are never stored: each lane re-generates them from the shared code-length runs and
 // keeps only the 19 symbol counts, two code-length-code tables and its tree scratch in LDS.
 // ---------------------------------------------------------------------------------------
+// one code-length tree per lane: 16-bit queue entries (weight < 1024, node id < 64), depths in the queue's memory
+typedef TreeMem<uint16_t, uint8_t, 20, 6, true> D4GHdrTree;
 struct D4GHdrLds {
     alignas(16) uint8_t lens[D4G_NLIT + D4G_NDIST];
     uint8_t runV[D4G_MAXPAIRS];
     uint16_t runL[D4G_MAXPAIRS];
     int nRuns;              // runs whose packing depends on the flags (the others are summed in baseFreq)
     uint32_t baseFreq[20];  // code-length symbols contributed by the runs every candidate packs as plain literals
-    alignas(16) unsigned char tree[TreeMem<uint32_t, uint8_t, 20>::bytes(64)];
+    alignas(16) unsigned char tree[D4GHdrTree::bytes(64)];
     uint16_t freq[19 * 64];
     uint8_t cl0[19 * 64];
     uint8_t cl1[19 * 64];
 };
 
-__device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits) {
-    TreeMem<uint32_t, uint8_t, 20> tm;
+__device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits, long long* prof = nullptr) {
+#ifdef D4G_PROFILE_OPS
+    long long q0 = d4g_clock_drained();
+#endif
+    D4GHdrTree tm;
     tm.carve(H->tree, 64);
 #define FQ(s) H->freq[(s) * 64 + lane]
 #define C0(s) H->cl0[(s) * 64 + lane]
@@ -957,9 +972,24 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
     int nRuns = H->nRuns;
     for (int s = 0; s < 19; s++) { FQ(s) = (uint16_t)H->baseFreq[s]; C0(s) = 0; C1(s) = 0; }
     // rewriteHeader(flags): symbol counts of the packed lengths
-    for (int r = 0; r < nRuns; r++)
-        d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int, int) { FQ(sym)++; });
+    // The repeat symbols are counted in registers; each run touches LDS once, for its own (wave-uniform) value.
+    {
+        int c16 = 0, c17 = 0, c18 = 0;
+        for (int r = 0; r < nRuns; r++) {
+            const int v = H->runV[r];
+            d4g_pack_kinds(v, H->runL[r], flags,
+                           [&](int sym, int, int, int cnt) { if (sym == 16) c16 += cnt; else if (sym == 17) c17 += cnt; else c18 += cnt; },
+                           [&](int cnt) { FQ(v) += (uint16_t)cnt; });
+        }
+        FQ(16) += (uint16_t)c16; FQ(17) += (uint16_t)c17; FQ(18) += (uint16_t)c18;
+    }
+#ifdef D4G_PROFILE_OPS
+    long long q1 = d4g_clock_drained();
+#endif
     d4g_build_tree(tm, 64, lane, 19, 7, [&](int i) { return (unsigned)FQ(i); }, [&](int v, int len) { C0(v) = (uint8_t)len; });
+#ifdef D4G_PROFILE_OPS
+    long long q2 = d4g_clock_drained();
+#endif
     long long hdr = 5 + 5 + 4 + 19 * 3;
     for (int s = 0; s < 19; s++) hdr += (long long)FQ(s) * (C0(s) + (s >= 16 ? pair_extra_bits(s) : 0));
     int nCl = trim_codelens(19, [&](int s) { return (int)C0(s); });
@@ -968,11 +998,29 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
     if (prune) {
         // recodeHeaderToLessRLEMatches: expand runs that are not shorter than literals, then re-derive the code
         for (int s = 0; s < 19; s++) FQ(s) = (uint16_t)H->baseFreq[s];
-        for (int r = 0; r < nRuns; r++)
-            d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int run, int value) {
-                if (sym >= 16 && pair_replace_gain(sym, run, value, true, [&](int s) { return (int)C0(s); }) >= 0) FQ(value) += run;
-                else FQ(sym)++;
-            });
+        {
+            const int l16 = C0(16), l17 = C0(17), l18 = C0(18), l0 = C0(0);
+            int c16 = 0, c17 = 0, c18 = 0, z = 0;
+            for (int r = 0; r < nRuns; r++) {
+                const int v = H->runV[r];
+                const int lv = C0(v);
+                int addV = 0;
+                d4g_pack_kinds(v, H->runL[r], flags,
+                               [&](int sym, int run, int, int cnt) {
+                                   // sym 16 repeats `v`, 17 / 18 repeat zero
+                                   int lsym = sym == 16 ? l16 : sym == 17 ? l17 : l18;
+                                   int lval = sym == 16 ? lv : l0;
+                                   bool expand = pair_gain_bits(sym, run, lsym, lval, true) >= 0;
+                                   if (expand) { if (sym == 16) addV += run * cnt; else z += run * cnt; }
+                                   else if (sym == 16) c16 += cnt;
+                                   else if (sym == 17) c17 += cnt;
+                                   else c18 += cnt;
+                               },
+                               [&](int cnt) { addV += cnt; });
+                if (addV) FQ(v) += (uint16_t)addV;
+            }
+            FQ(16) += (uint16_t)c16; FQ(17) += (uint16_t)c17; FQ(18) += (uint16_t)c18; FQ(0) += (uint16_t)z;
+        }
         d4g_build_tree(tm, 64, lane, 19, 7, [&](int i) { return (unsigned)FQ(i); }, [&](int v, int len) { C1(v) = (uint8_t)len; });
         nCl = trim_codelens(nCl, [&](int s) { return (int)C1(s); });
         hdr = 5 + 5 + 4 + 3 * nCl;
@@ -986,19 +1034,37 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
         nCl = n2;
     }
     long long saved = 0;
-    for (int r = 0; r < nRuns; r++)
-        d4g_pack_run(H->runV[r], H->runL[r], flags, [&](int sym, int run, int value) {
-            if (sym < 16) return;
-            if (useC1) {
-                if (pair_replace_gain(sym, run, value, true, [&](int s) { return (int)C0(s); }) >= 0) return;  // already literals
-                int g = pair_replace_gain(sym, run, value, false, [&](int s) { return (int)C1(s); });
-                if (g >= 0) saved += g;
-            } else {
-                int g = pair_replace_gain(sym, run, value, false, [&](int s) { return (int)C0(s); });
-                if (g >= 0) saved += g;
-            }
-        });
+    {
+        const int a16 = C0(16), a17 = C0(17), a18 = C0(18), a0 = C0(0);
+        const int b16 = C1(16), b17 = C1(17), b18 = C1(18), b0 = C1(0);
+        for (int r = 0; r < nRuns; r++) {
+            const int v = H->runV[r];
+            const int av = C0(v), bv = C1(v);
+            d4g_pack_kinds(v, H->runL[r], flags,
+                           [&](int sym, int run, int, int cnt) {
+                               int as = sym == 16 ? a16 : sym == 17 ? a17 : a18, al = sym == 16 ? av : a0;
+                               int g;
+                               if (useC1) {
+                                   if (pair_gain_bits(sym, run, as, al, true) >= 0) return;  // already literals
+                                   int bs = sym == 16 ? b16 : sym == 17 ? b17 : b18, bl = sym == 16 ? bv : b0;
+                                   g = pair_gain_bits(sym, run, bs, bl, false);
+                               } else {
+                                   g = pair_gain_bits(sym, run, as, al, false);
+                               }
+                               if (g >= 0) saved += (long long)g * cnt;
+                           },
+                           [&](int) {});
+        }
+    }
     hdr -= saved;
+#ifdef D4G_PROFILE_OPS
+    if (prof && lane == 0) {
+        atomicAdd((unsigned long long*)&prof[48], (unsigned long long)(q1 - q0));          // first count pass
+        atomicAdd((unsigned long long*)&prof[49], (unsigned long long)(q2 - q1));          // first tree
+        atomicAdd((unsigned long long*)&prof[50], (unsigned long long)(d4g_clock_drained() - q2));   // rest (lane 0 has no prune)
+        atomicAdd((unsigned long long*)&prof[51], 1ULL);
+    }
+#endif
 #undef FQ
 #undef C0
 #undef C1
@@ -1010,6 +1076,9 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     const D4GState* base = state_ptr(c, blk, op.src);
     long long* keyp = c.keys + (long long)blk * c.nOps + opId;
     int lane = threadIdx.x & 63;
+#ifdef D4G_PROFILE_OPS
+    long long h0 = d4g_clock_drained();
+#endif
     __syncthreads();
     if (!ld_state_i32(&base->valid) || ld_state_i32(&base->type) != D4G_DYNAMIC) {
         if (lane == 0) *keyp = D4G_KEY_NONE;
@@ -1069,13 +1138,24 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
         if (lane == 0) H.nRuns = ncx;
     }
     __syncthreads();
+#ifdef D4G_PROFILE_OPS
+    long long h1 = d4g_clock_drained();
+#endif
     long long key = D4G_KEY_NONE;
     if (lane < 56) {
-        long long size = d4g_hdr_candidate(&H, lane, c.hdrFlags[lane], c.hdrPrune[lane], baseLitlenBits);
+        long long size = d4g_hdr_candidate(&H, lane, c.hdrFlags[lane], c.hdrPrune[lane], baseLitlenBits, c.opStats);
         key = D4G_MAKE_KEY(size, (long long)opId * 64 + lane);
     }
     key = wave_min_i64(key);
     if (lane == 0) *keyp = key;
+#ifdef D4G_PROFILE_OPS
+    if (c.opStats && lane == 0) {
+        atomicAdd((unsigned long long*)&c.opStats[52], (unsigned long long)(h1 - h0));          // load + runs
+        atomicAdd((unsigned long long*)&c.opStats[53], (unsigned long long)(d4g_clock_drained() - h1));   // candidates (all lanes)
+        atomicAdd((unsigned long long*)&c.opStats[54], 1ULL);
+        atomicAdd((unsigned long long*)&c.opStats[55], (unsigned long long)H.nRuns);
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {

@@ -251,6 +251,22 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
 
 void d4g_free(void* p) { free(p); }
 
+#ifdef D4G_HOSTSIM
+// emulator builds only: the closed-form pack summary against the reference-shaped loop, every flag set and run length
+long long d4g_test_pack_kinds(void) {
+    long long bad = 0;
+    for (int flags = 0; flags < 256; flags++)
+        for (int v = 0; v <= 7; v += 7)
+            for (int r = 1; r <= 420; r++) {
+                int a[19 * 160] = {0}, b[19 * 160] = {0};
+                d4g_pack_run(v, r, flags, [&](int sym, int run, int) { a[sym * 160 + run]++; });
+                d4g_pack_kinds(v, r, flags, [&](int sym, int run, int, int cnt) { b[sym * 160 + run] += cnt; }, [&](int cnt) { b[v * 160] += cnt; });
+                for (int i = 0; i < 19 * 160; i++) bad += a[i] != b[i];
+            }
+    return bad;
+}
+#endif
+
 #ifdef D4G_PROFILE_OPS
 // profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
 int d4g_debug_set_experiment(long long mode) {

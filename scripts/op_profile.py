@@ -22,12 +22,17 @@ for it in range(2):
 buf = (ctypes.c_longlong * 64)()
 L.d4g_debug_opstats(buf)
 names = {1: "OPT", 2: "RECODE", 3: "FULL", 4: "LEAST", 5: "POST", 6: "PRUNEHDR", 7: "TOFIXED"}
-print("ms_optimise %.1f state_ms %.1f" % (st["ms_optimise"], st["ms_state_kernels"]))
+print("ms_optimise %.1f state_ms %.1f search_ms %.1f" % (st["ms_optimise"], st["ms_state_kernels"], st["ms_search_kernels"]))
 if buf[23]:
     print("OPT sections (mean cycles): load %.0f  token pass %.0f  optimise_header %.0f" % (buf[20] / buf[23], buf[21] / buf[23], buf[22] / buf[23]))
 if buf[27]:
     print("recode_huffman sections (mean cycles): lit tree %.0f  dist-tree wait %.0f  sizes+header %.0f  (n=%d)"
           % (buf[24] / buf[27], buf[25] / buf[27], buf[26] / buf[27], buf[27]))
+if buf[54]:
+    print("hdr search (mean cycles): load+runs %.0f  candidates %.0f  (n=%d); lane 0: count pass %.0f  tree %.0f  rest %.0f"
+          % (buf[52] / buf[54], buf[53] / buf[54], buf[54], buf[48] / max(1, buf[51]), buf[49] / max(1, buf[51]), buf[50] / max(1, buf[51])))
+if buf[54]:
+    print("hdr search: mean flag-dependent runs per op %.1f" % (buf[55] / buf[54]))
 for arg in (0, 1):
     for k, nm in names.items():
         cyc, n = buf[k * 2 + arg * 32], buf[k * 2 + 1 + arg * 32]

@@ -97,3 +97,12 @@ def test_wave_wide_tree_builder_in_the_emulator():
     r = b.result(0)
     assert r["status"] == rc and r["saved_bits"] == saved and b.output(0) == (want if rc == 0 else a)
     b.close()
+
+
+def test_pack_summary_matches_the_pair_by_pair_packing(sim):
+    """d4g_pack_kinds (closed form, used by the header search) == d4g_pack_run (HuffmanTable.pack's loops) as
+    multisets of pairs, for all 256 flag sets, zero / non-zero values and run lengths 1..420."""
+    D, L = sim
+    import ctypes
+    L.d4g_test_pack_kinds.restype = ctypes.c_longlong
+    assert L.d4g_test_pack_kinds() == 0
