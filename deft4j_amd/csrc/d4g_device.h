@@ -348,8 +348,17 @@ D4G_DEV void d4g_wave_sync() { __builtin_amdgcn_wave_barrier(); }  // LDS access
 struct D4GWaveHeap {
     int w0, i0;
     uint64_t* deep;   // LDS, slots >= 64: weight << 32 | id
+    // register slots (k < 64)
+    D4G_DEV unsigned regW(int k) const { return (unsigned)d4g_readlane(w0, k); }
+    D4G_DEV int regI(int k) const { return d4g_readlane(i0, k); }
+    D4G_DEV void regPut(int k, unsigned ww, int ii) {
+        const bool me = (int)(threadIdx.x & 63) == k;
+        w0 = me ? (int)ww : w0;
+        i0 = me ? ii : i0;
+    }
+    // any slot
     D4G_DEV void get(int k, unsigned& ww, int& ii) const {
-        if (k < 64) { ww = (unsigned)d4g_readlane(w0, k); ii = d4g_readlane(i0, k); }
+        if (k < 64) { ww = regW(k); ii = regI(k); }
         else {
             uint64_t e = deep[k];
             ww = (unsigned)d4g_uniform((int)(e >> 32));
@@ -357,9 +366,8 @@ struct D4GWaveHeap {
         }
     }
     D4G_DEV void put(int k, unsigned ww, int ii) {
-        const int lane = threadIdx.x & 63;
-        if (k < 64) { w0 = lane == k ? (int)ww : w0; i0 = lane == k ? ii : i0; }
-        else if (lane == 0) deep[k] = ((uint64_t)ww << 32) | (uint32_t)ii;
+        if (k < 64) regPut(k, ww, ii);
+        else if ((threadIdx.x & 63) == 0) deep[k] = ((uint64_t)ww << 32) | (uint32_t)ii;
     }
 };
 
@@ -388,24 +396,42 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
         hp.put(k, wx, idx);
     };
     auto pq_remove = [&](unsigned& rw, int& ri) D4G_LAMBDA_INLINE {
-        hp.get(0, rw, ri);
+        rw = hp.regW(0);
+        ri = hp.regI(0);
         int s = --hs;
         if (s != 0) {
             unsigned xw; int xi;
             hp.get(s, xw, xi);
-            int k = 0, half = s >> 1;
-            while (k < half) {
+            int k = 0;
+            const int half = s >> 1;
+            // levels whose children are both register slots: no region checks, the child's id is read only once chosen
+            const int regHalf = half < 31 ? half : 31;   // k < 31  =>  2k + 2 < 64
+            bool placed = false;
+            while (k < regHalf) {
                 int child = 2 * k + 1;
-                unsigned cw; int ci;
-                hp.get(child, cw, ci);
+                unsigned cw = hp.regW(child);
                 if (child + 1 < s) {
-                    unsigned rw2; int ri2;
-                    hp.get(child + 1, rw2, ri2);
-                    if (cw > rw2) { cw = rw2; ci = ri2; child = child + 1; }
+                    unsigned rw2 = hp.regW(child + 1);
+                    if (cw > rw2) { cw = rw2; child = child + 1; }
                 }
-                if (xw <= cw) break;
-                hp.put(k, cw, ci);
+                if (xw <= cw) { placed = true; break; }
+                hp.regPut(k, cw, hp.regI(child));
                 k = child;
+            }
+            if (!placed) {
+                while (k < half) {   // the rest of the path (slots in LDS)
+                    int child = 2 * k + 1;
+                    unsigned cw; int ci;
+                    hp.get(child, cw, ci);
+                    if (child + 1 < s) {
+                        unsigned rw2; int ri2;
+                        hp.get(child + 1, rw2, ri2);
+                        if (cw > rw2) { cw = rw2; ci = ri2; child = child + 1; }
+                    }
+                    if (xw <= cw) break;
+                    hp.put(k, cw, ci);
+                    k = child;
+                }
             }
             hp.put(k, xw, xi);
         }
