@@ -289,18 +289,39 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
                 while (lw.rem > 0) lw_step(lw, Uw, lc);
                 total = lw.total;
             }
-            // long back-references: the whole wave sums one record at a time (coalesced byte loads)
+            // long back-references: the whole wave sums them (coalesced byte loads), two at a time with all their
+            // loads in flight together
             unsigned long long ml = __ballot(act && isLong);
             while (ml) {
-                int srcLane = __ffsll((long long)ml) - 1;
+                int srcA = __ffsll((long long)ml) - 1;
                 ml &= ml - 1;
-                uint32_t o2 = (uint32_t)d4g_readlane((int)cur.y, srcLane);
-                int l2 = d4g_readlane(len, srcLane);
-                const uint8_t* p2 = Ub + o2;
-                int part = 0;
-                for (int k = lane; k < l2; k += 64) part += lc[p2[k]];
-                int tsum = wave_sum_i32(part);
-                if (lane == srcLane) total = tsum;
+                int srcB = ml ? __ffsll((long long)ml) - 1 : -1;
+                if (srcB >= 0) ml &= ml - 1;
+                const uint8_t* pA = Ub + (uint32_t)d4g_readlane((int)cur.y, srcA);
+                const int lA = d4g_readlane(len, srcA);
+                const uint8_t* pB = pA;
+                int lB = 0;
+                if (srcB >= 0) { pB = Ub + (uint32_t)d4g_readlane((int)cur.y, srcB); lB = d4g_readlane(len, srcB); }
+                uint8_t ba[5], bb[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) {   // 258 bytes at most: five per lane
+                    int k = lane + 64 * j;
+                    ba[j] = k < lA ? pA[k] : (uint8_t)0;
+                    bb[j] = k < lB ? pB[k] : (uint8_t)0;
+                }
+                int partA = 0, partB = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    int k = lane + 64 * j;
+                    if (k < lA) partA += lc[ba[j]];
+                    if (k < lB) partB += lc[bb[j]];
+                }
+                int tA = wave_sum_i32(partA);
+                if (lane == srcA) total = tA;
+                if (srcB >= 0) {
+                    int tB = wave_sum_i32(partB);
+                    if (lane == srcB) total = tB;
+                }
             }
             if (act) {
                 if (total >= D4G_NO_CODE) atomicOr(&flags[0], 1u << bin);   // a byte without a code: the bin is not allowed
