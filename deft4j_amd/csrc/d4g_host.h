@@ -479,6 +479,7 @@ struct Batch {
     bool ran = false;
 
     ~Batch() {
+        try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
         rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
@@ -1254,6 +1255,23 @@ struct Batch {
         stats.ms_search_kernels = msSearch;
         stats.ms_parse_kernels = msParseKernels;
         stats.search_bytes_algorithmic = stats.bytes_in + stats.bytes_decoded + stats.bytes_out;
+        release_scratch();
+    }
+    // After the write phase only the results are needed (output words, decoded bytes, stream table): the search's
+    // working set goes back to the memory pool, where the next batch finds it.
+    void release_scratch() {
+        rt_sync_all();
+        rt_free(dTok); dTok = nullptr;
+        rt_free(dRefs); dRefs = nullptr;
+        rt_free(dTokRef); dTokRef = nullptr;
+        rt_free(dBlocks); dBlocks = nullptr;
+        rt_free(dStates); dStates = nullptr;
+        rt_free(dMasks); dMasks = nullptr;
+        rt_free(dKeys); dKeys = nullptr;
+        rt_free(dActive); dActive = nullptr;
+        rt_free(dResults); dResults = nullptr;
+        rt_free(dReady); dReady = nullptr;
+        rt_free(dHeads); dHeads = nullptr;
     }
 };
 

@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <map>
 #include <string>
+#include <unordered_map>
 
 #ifndef D4G_HOSTSIM
 #include <hip/hip_runtime.h>
@@ -33,12 +35,65 @@ inline RtGlobals& rt() {
     static RtGlobals g;
     return g;
 }
-inline void* rt_malloc(size_t n) {
-    void* p = nullptr;
-    RT_CHECK(hipMalloc(&p, n ? n : 16));
+// Device memory comes from a small caching pool: hipMalloc / hipFree cost milliseconds for the buffers a batch
+// needs (and vary a lot from host to host), so freed blocks are kept by size class and handed out again.
+// Callers free a block only after the work that used it has completed (they synchronise first), as hipFree's
+// implicit device synchronisation used to guarantee.
+struct RtPool {
+    std::multimap<size_t, void*> freeBlocks;      // capacity -> block
+    std::unordered_map<void*, size_t> capacity;   // every block the pool handed out or holds
+    size_t heldBytes = 0;                         // bytes sitting in freeBlocks
+    size_t maxHeldBytes = (size_t)64 << 30;       // D4G_POOL_MAX_MB overrides
+    static size_t size_class(size_t n) {          // 1/8-octave steps: at most 12.5 % slack
+        if (n < 4096) return 4096;
+        int hb = 63 - __builtin_clzll((unsigned long long)n);
+        size_t step = (size_t)1 << (hb - 3);
+        return (n + step - 1) & ~(step - 1);
+    }
+};
+inline RtPool& rt_pool() {
+    static RtPool p;
     return p;
 }
-inline void rt_free(void* p) { if (p) (void)hipFree(p); }
+inline void* rt_malloc(size_t n) {
+    RtPool& P = rt_pool();
+    size_t c = RtPool::size_class(n ? n : 16);
+    auto it = P.freeBlocks.find(c);
+    if (it != P.freeBlocks.end()) {
+        void* p = it->second;
+        P.freeBlocks.erase(it);
+        P.heldBytes -= c;
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, c);
+    if (e != hipSuccess && !P.freeBlocks.empty()) {   // out of memory: give the cached blocks back and retry
+        (void)hipGetLastError();
+        for (auto& kv : P.freeBlocks) { P.capacity.erase(kv.second); (void)hipFree(kv.second); }
+        P.freeBlocks.clear();
+        P.heldBytes = 0;
+        e = hipMalloc(&p, c);
+    }
+    if (e != hipSuccess) throw std::runtime_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+    P.capacity[p] = c;
+    return p;
+}
+inline void rt_free(void* p) {
+    if (!p) return;
+    RtPool& P = rt_pool();
+    auto it = P.capacity.find(p);
+    if (it == P.capacity.end()) { (void)hipFree(p); return; }
+    size_t c = it->second;
+    if (P.heldBytes + c > P.maxHeldBytes) { P.capacity.erase(it); (void)hipFree(p); return; }
+    P.freeBlocks.emplace(c, p);
+    P.heldBytes += c;
+}
+inline void rt_pool_release() {   // d4g_shutdown
+    RtPool& P = rt_pool();
+    for (auto& kv : P.freeBlocks) { P.capacity.erase(kv.second); (void)hipFree(kv.second); }
+    P.freeBlocks.clear();
+    P.heldBytes = 0;
+}
 inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().a[rt().cur])); }
 inline void rt_d2h(void* h, const void* d, size_t n) {
     if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().a[rt().cur]));
@@ -47,6 +102,12 @@ inline void rt_d2h(void* h, const void* d, size_t n) {
 inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().a[rt().cur])); }
 inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().a[rt().cur])); }
 inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().a[rt().cur])); }
+inline void rt_sync_all() {
+    for (int k = 0; k < RT_MAX_LANES; k++) {
+        if (rt().a[k]) RT_CHECK(hipStreamSynchronize(rt().a[k]));
+        if (rt().b[k]) RT_CHECK(hipStreamSynchronize(rt().b[k]));
+    }
+}
 #define RT_LAUNCH(kern, grid, block, ...)                                                           \
     do {                                                                                            \
         hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().a[rt().cur], __VA_ARGS__); \

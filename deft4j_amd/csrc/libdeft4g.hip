@@ -39,6 +39,7 @@ int d4g_init(int device_index) {
             if (!rt().b[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().b[k], hipStreamNonBlocking));
         }
         rt().device = device_index;
+        if (const char* mb = getenv("D4G_POOL_MAX_MB")) rt_pool().maxHeldBytes = (size_t)atoll(mb) << 20;
 #endif
         rt().ready = true;
         engine().init();
@@ -51,6 +52,9 @@ int d4g_init(int device_index) {
 void d4g_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     rt().ready = false;
+#ifndef D4G_HOSTSIM
+    rt_pool_release();
+#endif
 }
 
 d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len) {
