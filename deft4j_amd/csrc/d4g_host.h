@@ -563,20 +563,24 @@ struct Batch {
                 if (nc <= cap) break;
                 cap = nc + 1024;
             }
-            // 2. speculative probes
+            // 2. speculative probes; only the candidates that parse come back
+            stats.scan_candidates = (i64)nc;
             if (nc) {
-                D4GProbeOut* dPo = (D4GProbeOut*)rt_malloc((size_t)nc * sizeof(D4GProbeOut));
-                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, dPo, nc);
+                D4GProbeHit* dHits = (D4GProbeHit*)rt_malloc((size_t)nc * sizeof(D4GProbeHit));
+                rt_memset(dN, 0, 4);
+                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, (D4GProbeOut*)nullptr, nc, dHits, dN);
                 stats.kernel_launches++;
-                cands.resize(nc);
-                pout.resize(nc);
-                rt_d2h(cands.data(), dCands, (size_t)nc * sizeof(D4GProbeIn));
-                rt_d2h(pout.data(), dPo, (size_t)nc * sizeof(D4GProbeOut));
-                rt_free(dPo);
+                unsigned nh = 0;
+                rt_d2h(&nh, dN, 4);
+                std::vector<D4GProbeHit> hits(nh);
+                rt_d2h(hits.data(), dHits, (size_t)nh * sizeof(D4GProbeHit));
+                rt_free(dHits);
+                cands.resize(nh);
+                pout.resize(nh);
+                for (unsigned k = 0; k < nh; k++) { cands[k] = hits[k].in; pout[k] = hits[k].out; }
             }
             rt_free(dCands); rt_free(dN); rt_free(dTiles);
         }
-        stats.scan_candidates = (i64)cands.size();
         // candidate maps: bit position -> probe result
         std::vector<std::vector<std::pair<i64, int>>> byStream(n);
         for (size_t k = 0; k < cands.size(); k++)
@@ -618,7 +622,7 @@ struct Batch {
             }
             if (ex.empty()) break;
             rt_h2d(dEx, ex.data(), ex.size() * sizeof(D4GProbeIn));
-            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size());
+            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GProbeHit*)nullptr, (unsigned*)nullptr);
             stats.kernel_launches++;
             stats.exact_probes += (i64)ex.size();
             std::vector<D4GProbeOut> eo(ex.size());

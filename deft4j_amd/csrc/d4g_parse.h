@@ -565,13 +565,27 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     }
 }
 
-__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n) {
+// With `hits` set, only the candidates that parse are reported, compacted (the scan's candidates are mostly
+// false positives; the host reads back a few hundred records instead of all of them).
+struct D4GProbeHit { D4GProbeIn in; D4GProbeOut out; };
+__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
+                                                     D4GProbeHit* hits, unsigned* nHits) {
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
     D4GParseOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
-    if ((threadIdx.x & 63) == 0) outp[blockIdx.x] = po;
+    if ((threadIdx.x & 63) == 0) {
+        if (hits) {
+            if (po.status == 0) {
+                unsigned k = atomicAdd(nHits, 1u);
+                hits[k].in = pi;
+                hits[k].out = po;
+            }
+        } else {
+            outp[blockIdx.x] = po;
+        }
+    }
 }
 
 // Emit: one wave per block decodes it again, now writing tokens, back-reference records, the block's
