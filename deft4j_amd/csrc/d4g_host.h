@@ -300,6 +300,18 @@ struct Program {
         hdrLevels.assign(nLevels, {});
         for (size_t i = 0; i < ops.size(); i++)
             (ops[i].kind == OP_HDRSEARCH ? hdrLevels : stateLevels)[opLevel[i]].push_back((int)i);
+        // Within a level the ops are independent; the long ones are dispatched first so that the short ones fill the
+        // launch's tail (execution order only — candidate ranking goes by op id).
+        auto cost = [&](int id) {
+            switch (ops[id].kind) {
+            case OP_LEAST: return 10;
+            case OP_RECODE_FULL: return 8;
+            case OP_RECODE: return (ops[id].arg & 1) ? 6 : 4;
+            case OP_OPT: case OP_TOFIXED_OPT: return 2;
+            default: return 1;
+            }
+        };
+        for (auto& v : stateLevels) std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return cost(x) > cost(y); });
     }
     void upload() {
         dOps = (D4GOp*)rt_malloc(ops.size() * sizeof(D4GOp));
