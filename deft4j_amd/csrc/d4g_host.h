@@ -304,10 +304,9 @@ struct Program {
         // launch's tail (execution order only — candidate ranking goes by op id).
         auto cost = [&](int id) {
             switch (ops[id].kind) {
-            case OP_LEAST: return 10;
             case OP_RECODE_FULL: return 8;
             case OP_RECODE: return (ops[id].arg & 1) ? 6 : 4;
-            case OP_OPT: case OP_TOFIXED_OPT: return 2;
+            case OP_OPT: case OP_TOFIXED_OPT: case OP_LEAST: return 2;
             default: return 1;
             }
         };
@@ -474,6 +473,8 @@ struct Batch {
     uint2* dTok = nullptr;
     uint2* dRefs = nullptr;       // back-reference records
     uint32_t* dTokRef = nullptr;  // token -> record index
+    uint32_t* dBinStat = nullptr; // per block: static bin statistics (d4g_types.h)
+    uint64_t* dBinMask = nullptr; // per block: bin record masks
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -492,14 +493,14 @@ struct Batch {
 
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
-        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -659,7 +660,8 @@ struct Batch {
         int masksAlloc = needSlots ? E.masksPerBlock : 1;
         hBlocks.clear();
         gpuType.clear();
-        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0;
+        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0, binMaskWords = 0;
+        std::vector<int32_t> realBlocks;   // device blocks that come straight from the parse (not merge arenas)
         std::vector<D4GStreamDesc> sd(n);
         std::vector<D4GEmitIn> emits;
         std::vector<D4GTokRange> ranges;
@@ -679,6 +681,9 @@ struct Batch {
             b.maskWords = (refCount + 63) / 64;
             b.refStart = refStart;
             b.refCount = refCount;
+            b.binStat = needSlots ? (i64)hBlocks.size() * D4G_NBINS * D4G_BINSTRIDE : -1;
+            b.binMask = binMaskWords;
+            if (needSlots) binMaskWords += (i64)D4G_NBINS * maskWordsCap;
             maskWordsTotal += maskWordsCap * masksAlloc;
             hBlocks.push_back(b);
             gpuType.push_back(type);
@@ -729,6 +734,7 @@ struct Batch {
                     hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.refStart, hb.refCount, hb.uStart, hb.uLen, (hb.refCount + 63) / 64,
                                        pb.type);
                     em.stateIdx = hBlocks[hb.gpu].stateIdx;
+                    realBlocks.push_back(hb.gpu);
                     nHuff++;
                 }
                 emits.push_back(em);
@@ -769,7 +775,13 @@ struct Batch {
             dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
             dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
             // mask 0 of every block starts empty (no back-reference expanded)
-            if (needSlots) rt_memset(dMasks, 0, (size_t)maskWordsTotal * 8);   // one fill instead of one per block
+            if (needSlots) {
+                rt_memset(dMasks, 0, (size_t)maskWordsTotal * 8);   // one fill instead of one per block
+                dBinStat = (uint32_t*)rt_malloc(nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
+                dBinMask = (uint64_t*)rt_malloc((size_t)binMaskWords * 8 + 64);
+                rt_memset(dBinStat, 0, nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
+                rt_memset(dBinMask, 0, (size_t)binMaskWords * 8 + 64);
+            }
         }
         RtEvent e0, e1;
         e0.record();
@@ -809,11 +821,21 @@ struct Batch {
                 if (bad[i]) throw std::runtime_error("parse: back-reference before the start of stream (host check missed it)");
             rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged);
         }
+        // 5. static bin statistics of every block's back-reference records (the least-expensive pass works from them)
+        int32_t* dReal = nullptr;
+        if (needSlots && !realBlocks.empty()) {
+            dReal = (int32_t*)rt_malloc(realBlocks.size() * 4);
+            rt_h2d(dReal, realBlocks.data(), realBlocks.size() * 4);
+            D4GCtx c = make_ctx(E.progDyn, 0);
+            RT_LAUNCH(k_block_bins, realBlocks.size(), 256, c, dReal);
+            stats.kernel_launches++;
+        }
         e1.record();
         rt_sync();
         msParseKernels += rt_elapsed_ms(e0, e1);
         rt_free(dSrc);
         dSrc = nullptr;
+        rt_free(dReal);
         check_device_errors();
     }
 
@@ -1280,6 +1302,8 @@ struct Batch {
         rt_free(dTok); dTok = nullptr;
         rt_free(dRefs); dRefs = nullptr;
         rt_free(dTokRef); dTokRef = nullptr;
+        rt_free(dBinStat); dBinStat = nullptr;
+        rt_free(dBinMask); dBinMask = nullptr;
         rt_free(dBlocks); dBlocks = nullptr;
         rt_free(dStates); dStates = nullptr;
         rt_free(dMasks); dMasks = nullptr;

@@ -36,6 +36,8 @@ struct D4GCtx {
     const uint2* tok;         // {token word, decoded-byte offset}
     const uint2* refs;        // back-reference records {packed symbols/length, decoded-byte offset}
     const uint32_t* tokRef;   // token -> back-reference record index
+    uint32_t* binStat;        // per block and length symbol: static statistics of its records (d4g_types.h)
+    uint64_t* binMask;        // per block and length symbol: which records carry it
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -239,136 +241,217 @@ __device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& 
 }
 
 // ---------------------------------------------------------------------------------------
-// removeDistLitLeastExpensive — DeflateBlockHuffman.java:373-458.
+// Static per-bin statistics of a block's back-reference records (D4G_NBINS rows, d4g_types.h) and the per-bin
+// record masks.  One workgroup per block, once per parse.
 // ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blockList) {
+    __shared__ uint32_t T[D4G_NBINS * D4G_BINSTRIDE];
+    const D4GBlock b = c.blocks[blockList[blockIdx.x]];
+    if (b.binStat < 0) return;
+    for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) T[i] = 0;
+    __syncthreads();
+    const uint2* rf = c.refs + b.refStart;
+    const uint8_t* Ub = c.U + b.uBase;
+    uint64_t* bm = c.binMask + b.binMask;
+    const int lane = threadIdx.x & 63;
+    const int nRef = (int)b.refCount, nWords = (int)b.maskWords;
+    for (int r0 = 0; r0 < nWords * 64; r0 += blockDim.x) {
+        int r = r0 + threadIdx.x;
+        uint2 rv = r < nRef ? rf[r] : make_uint2(0u, 0u);
+        int len = ref_len(rv.x);
+        int bin = ref_lsym(rv.x) - 257;
+        if (len > 0) {
+            uint32_t* row = T + bin * D4G_BINSTRIDE;
+            atomicAdd(&row[D4G_BIN_DIST + ref_dsym(rv.x)], 1u);
+            atomicAdd(&row[D4G_BIN_COUNT], 1u);
+            atomicAdd(&row[D4G_BIN_EBITS], (unsigned)ref_ebits(rv.x));
+            for_bytes(Ub + rv.y, len, [&](int by) { atomicAdd(&row[by], 1u); return true; });
+        }
+        // the bin masks: one ballot per bin present in this word of records
+        unsigned long long todo = __ballot(len > 0);
+        while (todo) {
+            int src = __ffsll((long long)todo) - 1;
+            int bsel = __shfl(bin, src);
+            unsigned long long same = __ballot(len > 0 && bin == bsel);
+            if (lane == src) bm[(long long)bsel * nWords + (r >> 6)] = same;
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    uint32_t* g = c.binStat + b.binStat;
+    for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) g[i] = T[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// removeDistLitLeastExpensive — DeflateBlockHuffman.java:373-458.
+// For every length symbol ("bin") the reference sums, over the bin's back-references, literal bits minus
+// back-reference bits, counts them, and disallows bins holding a byte without a code; it then expands the whole
+// bin that is cheapest (mode 0) or rarest (mode 1).  All of those sums are linear in the block's static bin
+// statistics (k_block_bins), so they are taken from the table under the state's code and corrected by walking
+// only the records that are already expanded (few); a mask with more expanded than unexpanded records is walked
+// the other way round.  Expanding the chosen bin is an OR with the bin's record mask plus the same kind of
+// table-minus-correction update of the histogram.
+// ---------------------------------------------------------------------------------------
+// literal bits of one record with the NO_CODE bytes counted in the high part (total = bits + D4G_NO_CODE * missing)
+D4G_DEV int d4g_ref_lit_total(const uint32_t* Uw, const uint16_t* lc, uint32_t off, int len) {
+    D4GLitWalk lw;
+    lw_start(lw, Uw, off, len);
+    while (lw.rem > 0) lw_step(lw, Uw, lc);
+    return lw.total;
+}
+// Calls fn(record index, record) for the records whose bit is set in sel(w) (w = mask word index), 64 at a time:
+// set bits are queued in LDS until a full wave's worth is there, so the lanes stay busy on sparse selections.
+template <typename Sel, typename Fn>
+D4G_DEV void wave_for_selected(int wave, int nw, int nWords, int nRef, const uint2* rf, uint32_t* queue /* [128] per wave */, Sel sel,
+                               Fn fn) {
+    const int lane = threadIdx.x & 63;
+    int pending = 0;
+    for (int w = wave; w < nWords; w += nw) {
+        unsigned long long m = sel(w);
+        if (w == nWords - 1 && (nRef & 63)) m &= (1ULL << (nRef & 63)) - 1;
+        int n = __popcll(m);
+        if ((m >> lane) & 1) queue[pending + __popcll(m & ((1ULL << lane) - 1))] = (uint32_t)(w * 64 + lane);
+        pending += n;
+        d4g_wave_sync();
+        if (pending >= 64) {
+            uint32_t r = queue[lane];
+            fn((int)r, rf[r]);
+            d4g_wave_sync();
+            uint32_t carry = lane < pending - 64 ? queue[64 + lane] : 0u;
+            d4g_wave_sync();
+            if (lane < pending - 64) queue[lane] = carry;
+            pending -= 64;
+            d4g_wave_sync();
+        }
+    }
+    if (lane < pending) {
+        uint32_t r = queue[lane];
+        fn((int)r, rf[r]);
+    }
+}
+
 __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut, int mode) {
     D4GState* S = &L->st;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int* binSize = L->misc;        // [32]
     int* binFreq = L->misc + 32;   // [32]
     unsigned* flags = (unsigned*)L->red;  // [0] noAllow bits, [1] seen bits, [2] chosen bin + 1
+    // scratch in the (idle) literal/length tree memory
+    int* binZ = (int*)L->treeLit;                      // [32] bytes without a code, per bin
+    int* delta = binZ + 32;                            // [320] histogram correction of the chosen bin
+    uint32_t* queues = (uint32_t*)(delta + 320);       // [8][128]: at most eight waves walk records
+    unsigned* npop = (unsigned*)(queues + 128 * 8);    // [1] expanded records in the mask
+    static_assert(sizeof(L->treeLit) >= (32 + 320 + 128 * 8 + 1) * 4, "scratch does not fit the tree memory");
+    const int nwq = nw < 8 ? nw : 8;
     __syncthreads();
     if (threadIdx.x < 64) L->misc[threadIdx.x] = 0;
+    if (threadIdx.x < 32) binZ[threadIdx.x] = 0;
     if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+    if (threadIdx.x == 0) *npop = 0;
     wg_fill_lit_cost(L);
     const uint16_t* lc = L->litCost;
     const uint2* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     const uint32_t* Uw = (const uint32_t*)Ub;
     const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
+    const uint32_t* stat = c.binStat + b.binStat;
+    const uint64_t* bmask = c.binMask + b.binMask;
+    {
+        unsigned pc = 0;
+        for (int w = threadIdx.x; w < nWords; w += blockDim.x) pc += (unsigned)__popcll(ld_sc1(maskIn + w));
+        if (pc) atomicAdd(npop, pc);
+    }
+    __syncthreads();
+    bool viaExpanded = 2 * (int)*npop <= nRef;   // walk the smaller side
+#ifdef D4G_HOSTSIM
+    if (getenv("D4G_SIM_LEAST_DIRECT")) viaExpanded = false;   // tests: force the other side
+#endif
     if (S->type == D4G_DYNAMIC) {
-        uint2 nrv = make_uint2(0u, 0u);
-        uint64_t nmw = 0;
-        if (wave < nWords) {
-            int r = wave * 64 + lane;
-            if (r < nRef) nrv = rf[r];
-            nmw = ld_sc1(maskIn + wave);
-        }
-        for (int w = wave; w < nWords; w += nw) {
-            uint2 cur = nrv;
-            uint64_t mw = nmw;
-            int w2 = w + nw;
-            if (w2 < nWords) {
-                int r2 = w2 * 64 + lane;
-                nrv = r2 < nRef ? rf[r2] : make_uint2(0u, 0u);
-                nmw = ld_sc1(maskIn + w2);
-            }
-            uint32_t a = cur.x;
-            int len = ref_len(a), cost = 0, bin = 0;
-            bool act = len > 0 && !((mw >> lane) & 1);
-            if (act) {
-                cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
-                bin = ref_lsym(a) - 257;
-                atomicOr(&flags[1], 1u << bin);
-            }
-            int total = 0;
-            const bool isLong = len > D4G_LONG_TOKEN;
-            if (act && !isLong) {
-                D4GLitWalk lw;
-                lw_start(lw, Uw, cur.y, len);
-                while (lw.rem > 0) lw_step(lw, Uw, lc);
-                total = lw.total;
-            }
-            // long back-references: the whole wave sums them (coalesced byte loads), two at a time with all their
-            // loads in flight together
-            unsigned long long ml = __ballot(act && isLong);
-            while (ml) {
-                int srcA = __ffsll((long long)ml) - 1;
-                ml &= ml - 1;
-                int srcB = ml ? __ffsll((long long)ml) - 1 : -1;
-                if (srcB >= 0) ml &= ml - 1;
-                const uint8_t* pA = Ub + (uint32_t)d4g_readlane((int)cur.y, srcA);
-                const int lA = d4g_readlane(len, srcA);
-                const uint8_t* pB = pA;
-                int lB = 0;
-                if (srcB >= 0) { pB = Ub + (uint32_t)d4g_readlane((int)cur.y, srcB); lB = d4g_readlane(len, srcB); }
-                uint8_t ba[5], bb[5];
-#pragma unroll
-                for (int j = 0; j < 5; j++) {   // 258 bytes at most: five per lane
-                    int k = lane + 64 * j;
-                    ba[j] = k < lA ? pA[k] : (uint8_t)0;
-                    bb[j] = k < lB ? pB[k] : (uint8_t)0;
+        if (viaExpanded) {
+            // table part: every record of the bin, under the state's code
+            for (int bin = wave; bin < D4G_NBINS; bin += nw) {
+                const uint32_t* row = stat + bin * D4G_BINSTRIDE;
+                int lit = 0, z = 0, cost = 0;
+                for (int i = lane; i < D4G_BINSTRIDE; i += 64) {
+                    int cnt = (int)row[i];
+                    if (i < 256) { int l = S->litLen[i]; lit += cnt * l; z += l ? 0 : cnt; }
+                    else if (i < D4G_BIN_COUNT) cost += cnt * S->distLen[i - D4G_BIN_DIST];
+                    else if (i == D4G_BIN_COUNT) cost += cnt * S->litLen[257 + bin];
+                    else if (i == D4G_BIN_EBITS) cost += cnt;
                 }
-                int partA = 0, partB = 0;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    int k = lane + 64 * j;
-                    if (k < lA) partA += lc[ba[j]];
-                    if (k < lB) partB += lc[bb[j]];
-                }
-                int tA = wave_sum_i32(partA);
-                if (lane == srcA) total = tA;
-                if (srcB >= 0) {
-                    int tB = wave_sum_i32(partB);
-                    if (lane == srcB) total = tB;
-                }
+                lit = wave_sum_i32(lit); z = wave_sum_i32(z); cost = wave_sum_i32(cost);
+                if (lane == 0) { binSize[bin] = lit - cost; binFreq[bin] = (int)row[D4G_BIN_COUNT]; binZ[bin] = z; }
             }
-            if (act) {
-                if (total >= D4G_NO_CODE) atomicOr(&flags[0], 1u << bin);   // a byte without a code: the bin is not allowed
-                else { atomicAdd(&binSize[bin], total - cost); atomicAdd(&binFreq[bin], 1); }
-            }
+            __syncthreads();
+            // correction: the expanded records do not count
+            if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ld_sc1(maskIn + w); },
+                              [&](int, uint2 rv) {
+                                  uint32_t a = rv.x;
+                                  int bin = ref_lsym(a) - 257;
+                                  int cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
+                                  int total = d4g_ref_lit_total(Uw, lc, rv.y, ref_len(a));
+                                  atomicSub(&binSize[bin], (total & (D4G_NO_CODE - 1)) - cost);
+                                  atomicSub(&binFreq[bin], 1);
+                                  if (total >= D4G_NO_CODE) atomicSub(&binZ[bin], total >> 14);
+                              });
+        } else {
+            if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ~ld_sc1(maskIn + w); },
+                              [&](int, uint2 rv) {
+                                  uint32_t a = rv.x;
+                                  int bin = ref_lsym(a) - 257;
+                                  int cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
+                                  int total = d4g_ref_lit_total(Uw, lc, rv.y, ref_len(a));
+                                  atomicAdd(&binSize[bin], (total & (D4G_NO_CODE - 1)) - cost);
+                                  atomicAdd(&binFreq[bin], 1);
+                                  if (total >= D4G_NO_CODE) atomicAdd(&binZ[bin], total >> 14);
+                              });
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int rem = -1, remSize = 0, remFreq = 0;
-        for (int i = 0; i < 32; i++) {
-            if (!((flags[0] >> i) & 1) && ((flags[1] >> i) & 1)) {
-                bool doRem = mode == 1 ? binFreq[i] < remFreq : binSize[i] < remSize;
-                if (rem == -1 || doRem) { rem = i; remSize = binSize[i]; remFreq = binFreq[i]; }
+        if (S->type == D4G_DYNAMIC) {
+            for (int i = 0; i < D4G_NBINS; i++) {
+                // seen: the bin has an unexpanded record; allowed: none of them holds a byte without a code
+                if (binFreq[i] > 0 && binZ[i] == 0) {
+                    bool doRem = mode == 1 ? binFreq[i] < remFreq : binSize[i] < remSize;
+                    if (rem == -1 || doRem) { rem = i; remSize = binSize[i]; remFreq = binFreq[i]; }
+                }
             }
+            S->sizeBits += remSize;
+            S->litlenBits += remSize;
         }
         flags[2] = (unsigned)(rem + 1);
-        if (S->type == D4G_DYNAMIC) { S->sizeBits += remSize; S->litlenBits += remSize; }
     }
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) delta[i] = 0;
     __syncthreads();
-    int rem = (int)flags[2] - 1;
-    for (int w = wave; w < nWords; w += nw) {
-        int r = w * 64 + lane;
-        uint2 cur = r < nRef ? rf[r] : make_uint2(0u, 0u);
-        uint64_t mw = ld_sc1(maskIn + w);
-        int bit = (int)((mw >> lane) & 1);
-        uint32_t a = cur.x;
-        int len = ref_len(a);
-        bool hit = rem >= 0 && len > 0 && !bit && ref_lsym(a) - 257 == rem;
-        if (hit) {
-            bit = 1;
-            atomicSub(&S->hist[ref_lsym(a)], 1u);
-            atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
+    const int rem = (int)flags[2] - 1;
+    if (rem < 0) {
+        for (int w = threadIdx.x; w < nWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(maskIn + w));
+        __syncthreads();
+        return;
+    }
+    // expand the bin: new mask = old | bin mask; the histogram loses the bin's unexpanded records' symbols and gains their bytes
+    const uint64_t* bm = bmask + (long long)rem * nWords;
+    for (int w = threadIdx.x; w < nWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(maskIn + w) | bm[w]);
+    // what the already expanded records of the bin contributed to the static row (they were moved earlier)
+    if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ld_sc1(maskIn + w) & bm[w]; },
+                      [&](int, uint2 rv) {
+                          uint32_t a = rv.x;
+                          atomicAdd(&delta[D4G_BIN_DIST + ref_dsym(a)], 1);
+                          atomicAdd(&delta[D4G_BIN_COUNT], 1);
+                          for_bytes(Ub + rv.y, ref_len(a), [&](int by) { atomicAdd(&delta[by], 1); return true; });
+                      });
+    __syncthreads();
+    {
+        const uint32_t* row = stat + rem * D4G_BINSTRIDE;
+        for (int i = threadIdx.x; i <= D4G_BIN_COUNT; i += blockDim.x) {
+            int moved = (int)row[i] - delta[i];
+            if (!moved) continue;
+            if (i < 256) atomicAdd(&S->hist[i], (unsigned)moved);
+            else if (i < D4G_BIN_COUNT) atomicSub(&S->hist[D4G_NLIT + i - D4G_BIN_DIST], (unsigned)moved);
+            else atomicSub(&S->hist[257 + rem], (unsigned)moved);
         }
-        if (hit && len <= D4G_LONG_TOKEN)
-            for_bytes(Ub + cur.y, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
-        unsigned long long ml = __ballot(hit && len > D4G_LONG_TOKEN);
-        while (ml) {
-            int srcLane = __ffsll((long long)ml) - 1;
-            ml &= ml - 1;
-            uint32_t o2 = __shfl(cur.y, srcLane);
-            int l2 = __shfl(len, srcLane);
-            const uint8_t* p2 = Ub + o2;
-            for (int k = lane; k < l2; k += 64) atomicAdd(&S->hist[p2[k]], 1u);
-        }
-        uint64_t nm = __ballot(bit);
-        if (lane == 0) st_sc1(maskOut + w, nm);
     }
     __syncthreads();
 }

@@ -15,6 +15,8 @@
 //             .x  length | (length symbol - 257) << 9 | distance symbol << 14 | extra bits << 19
 //             .y  offset of its decoded bytes in U
 //   tokRef[t] u32  index into refs of back-reference token t (the writer's way from a token to its mask bit)
+//   binStat / binMask  per block and length symbol: byte / distance-symbol / record statistics of its records and
+//             the bit mask of its records (static; see D4G_NBINS below)
 //   U[]       u8   decoded bytes of the whole stream, block after block
 //   State     ~3.3 KB per candidate: code lengths, header RLE pairs, symbol histogram, sizes
 //   masks     1 bit per back-reference: "this back-reference is expanded to literals".  The reference
@@ -32,6 +34,15 @@
 #define D4G_NDIST 32   // padded distance alphabet (30 used)
 #define D4G_HIST (D4G_NLIT + D4G_NDIST)
 #define D4G_MAXPAIRS 320
+// Static statistics of a block's back-reference records, one row per length symbol 257+b ("bin", the unit
+// removeDistLitLeastExpensive works in): [0,256) how often each byte value occurs in the bin's records' decoded
+// bytes, [256,286) how many of its records use each distance symbol, [286] its record count, [287] the sum of its
+// records' extra bits.  Every per-bin sum that pass needs is linear in these.
+#define D4G_NBINS 29
+#define D4G_BINSTRIDE 320
+#define D4G_BIN_DIST 256
+#define D4G_BIN_COUNT 286
+#define D4G_BIN_EBITS 287
 
 // Encoded RLE pair (u16): bits 0-4 sym (0..18); bits 5-12 X; bit 13 expanded-to-literals.
 //   literal length : X = 0, value = sym
@@ -69,6 +80,8 @@ struct D4GBlock {
     int64_t maskWords;   // u64 words per mask = ceil(refCount / 64)
     int64_t refStart;    // first back-reference record (index into refs); adjacent blocks are contiguous
     int64_t refCount;
+    int64_t binStat;     // first u32 of the block's per-length-symbol statistics (D4G_NBINS x D4G_BINSTRIDE), -1: none
+    int64_t binMask;     // first u64 of the block's per-length-symbol record masks (D4G_NBINS x maskWords)
 };
 
 // Ops of the candidate-search program (one optimiseBlock call = one program run per block).

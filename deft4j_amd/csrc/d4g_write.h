@@ -239,6 +239,30 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
         }
         mM[w] = v;
     }
+    // static bin statistics and bin masks of the merged block: rows add, masks concatenate like the token masks
+    if (bM.binStat >= 0) {
+        const uint32_t* gA = c.binStat + bA.binStat;
+        const uint32_t* gB = c.binStat + bB.binStat;
+        uint32_t* gM = c.binStat + bM.binStat;
+        for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) gM[i] = gA[i] + gB[i];
+        for (int bin = 0; bin < D4G_NBINS; bin++) {
+            const uint64_t* xA = c.binMask + bA.binMask + (long long)bin * bA.maskWords;
+            const uint64_t* xB = c.binMask + bB.binMask + (long long)bin * bB.maskWords;
+            uint64_t* xM = c.binMask + bM.binMask + (long long)bin * bM.maskWords;
+            for (long long w = threadIdx.x; w < bM.maskWords; w += blockDim.x) {
+                uint64_t v;
+                if (w < q) v = xA[w];
+                else {
+                    long long j = w - q;
+                    uint64_t lo = j < bB.maskWords ? xB[j] : 0;
+                    uint64_t prev = (j >= 1 && j - 1 < bB.maskWords) ? xB[j - 1] : 0;
+                    v = s ? ((lo << s) | (prev >> (64 - s))) : lo;
+                    if (j == 0 && s) v = (xA[q] & ((1ULL << s) - 1)) | (lo << s);
+                }
+                xM[w] = v;
+            }
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) { S->maskSlot = 0; S->valid = 1; S->flags = 0; }
     wg_store_state(state_ptr(c, job.blkM, 0), S);

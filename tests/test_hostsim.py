@@ -106,3 +106,16 @@ def test_pack_summary_matches_the_pair_by_pair_packing(sim):
     import ctypes
     L.d4g_test_pack_kinds.restype = ctypes.c_longlong
     assert L.d4g_test_pack_kinds() == 0
+
+
+def test_least_expensive_pass_both_directions(sim, monkeypatch):
+    """removeDistLitLeastExpensive works from the static bin statistics minus the expanded records; masks that are
+    mostly expanded are walked over the unexpanded records instead.  Force that second direction."""
+    D, L = sim
+    monkeypatch.setenv("D4G_SIM_LEAST_DIRECT", "1")
+    for stem in ("text.s00", "lz-twice-twice.s00"):
+        p = MAN[stem]
+        a = rd(stem + ".in.deflate")
+        b = D.Batch([a], lib=L).run(p["merge_blocks"])
+        assert b.result(0)["saved_bits"] == p["saved_bits"] and b.output(0) == rd(stem + ".out.deflate")
+        b.close()
