@@ -1,4 +1,4 @@
-"""Container wrappers around the device hot path: raw deflate, gzip, zlib.
+"""Container wrappers around the device hot path: raw deflate, gzip, zlib, PNG, zip.
 
 Host-side mirrors of K/RawDeflateFile.java, K/GZFile.java and K/ZLibFile.java (K/ = deft4j-container/
 src/main/java/com/github/NeRdTheNed/deft4j/container/): same fields, same read/write order, same quirks
@@ -269,10 +269,94 @@ class PNGFile:
         return bytes(out)
 
 
+class ZipFile:
+    """K/ZipFile.java:83-128 + K/lljzip/RecalculatingZipWriter.java:23-136.  The reference reads the
+    archive with the third-party lljzip `ZipIO.readStandard` (un-vendored; end-of-central-directory record ->
+    central directory -> local headers) — restated here for plain archives (no Zip64, no split archives), so this
+    row's parity is unpinned: no reference fixture exercises it.  Writing follows RecalculatingZipWriter line by
+    line: local headers take CRC and sizes from their central-directory entry, data descriptors are not re-emitted,
+    central-directory offsets are remapped, the end record is rebuilt."""
+    file_type = "Zip"                         # K/ZipFile.java:131
+    multi = True
+
+    def read(self, data):
+        d = bytes(data)
+        e = d.rfind(b"PK\x05\x06")
+        if e < 0 or e + 22 > len(d):
+            return False
+        (self.disk, self.start_disk, _n_here, n_total, cd_size, cd_off, clen) = struct.unpack("<HHHHIIH", d[e + 4:e + 22])
+        if n_total == 0xffff or cd_off == 0xffffffff:
+            return False                       # Zip64: "may be due to use of ... Zip64 features" (K/ZipFile.java:90-93)
+        self.comment = d[e + 22:e + 22 + clen]
+        self.central = []
+        p = cd_off
+        for _ in range(n_total):
+            if d[p:p + 4] != b"PK\x01\x02":
+                return False
+            f = struct.unpack("<HHHHHHIIIHHHHHII", d[p + 4:p + 46])
+            ent = dict(made_by=f[0], needed=f[1], flags=f[2], method=f[3], time=f[4], date=f[5], crc=f[6], csize=f[7],
+                       usize=f[8], disk_start=f[12], int_attr=f[13], ext_attr=f[14], offset=f[15])
+            q = p + 46
+            ent["name"] = d[q:q + f[9]]
+            ent["extra"] = d[q + f[9]:q + f[9] + f[10]]
+            ent["fcomment"] = d[q + f[9] + f[10]:q + f[9] + f[10] + f[11]]
+            self.central.append(ent)
+            p = q + f[9] + f[10] + f[11]
+        self.locals = []
+        for ent in sorted(self.central, key=lambda x: x["offset"]):
+            o = ent["offset"]
+            if d[o:o + 4] != b"PK\x03\x04":
+                return False
+            f = struct.unpack("<HHHHHIIIHH", d[o + 4:o + 30])
+            lf = dict(needed=f[0], flags=f[1], method=f[2], time=f[3], date=f[4], crc=f[5], csize=f[6], usize=f[7], cen=ent)
+            q = o + 30
+            lf["name"] = d[q:q + f[8]]
+            lf["extra"] = d[q + f[8]:q + f[8] + f[9]]
+            if lf["csize"] == 0 and (ent["csize"], ent["usize"], ent["crc"]) != (lf["csize"], lf["usize"], lf["crc"]):
+                lf["csize"], lf["usize"], lf["crc"] = ent["csize"], ent["usize"], ent["crc"]   # data descriptors (K/ZipFile.java:103-106)
+            q += f[8] + f[9]
+            lf["data"] = d[q:q + lf["csize"]]
+            self.locals.append(lf)
+        if not self.locals:
+            return False
+        self.members = [lf for lf in self.locals if lf["method"] == 8]   # DEFLATED only (K/ZipFile.java:98-100)
+        return True
+
+    def stream_payloads(self):
+        return [(lf["name"].decode("utf-8", "replace") if lf["name"] else DEFAULT_NAME, lf["data"]) for lf in self.members]
+
+    def write(self, deflate_outputs):
+        for lf, out in zip(self.members, deflate_outputs):   # syncStreams — K/ZipFile.java:46-68
+            lf["data"] = out
+            lf["csize"] = len(out)
+            lf["cen"]["csize"] = len(out)
+        out = bytearray()
+        new_off = {}
+        for lf in self.locals:
+            c = lf["cen"]
+            new_off[c["offset"]] = len(out)
+            out += struct.pack("<IHHHHHIIIHH", 0x04034b50, lf["needed"], lf["flags"], lf["method"], lf["time"], lf["date"],
+                               c["crc"], c["csize"] & 0xffffffff, c["usize"] & 0xffffffff, len(lf["name"]), len(lf["extra"]))
+            out += lf["name"] + lf["extra"] + lf["data"]
+        start_central = len(out)
+        for c in self.central:
+            out += struct.pack("<IHHHHHHIIIHHHHHII", 0x02014b50, c["made_by"], c["needed"], c["flags"], c["method"], c["time"],
+                               c["date"], c["crc"], c["csize"] & 0xffffffff, c["usize"] & 0xffffffff, len(c["name"]),
+                               len(c["extra"]), len(c["fcomment"]), c["disk_start"], c["int_attr"], c["ext_attr"],
+                               new_off[c["offset"]])
+            out += c["name"] + c["extra"] + c["fcomment"]
+        out += struct.pack("<IHHHHIIH", 0x06054b50, self.disk, self.start_disk, len(self.central), len(self.central),
+                           len(out) - start_central, start_central, len(self.comment))
+        out += self.comment
+        return bytes(out)
+
+
 def detect(data):
-    """K/ContainerUtil.java:64-86 by magic bytes (PNG, gzip, zlib); anything else must be given explicitly."""
+    """K/ContainerUtil.java:64-86 by magic bytes (PNG, zip, gzip, zlib); anything else must be given explicitly."""
     if bytes(data[:8]) == PNGFile.SIG:
         return PNGFile()
+    if bytes(data[:4]) == b"PK\x03\x04":
+        return ZipFile()
     d = bytes(data[:2])
     if d == b"\x1f\x8b":
         return GZFile()
@@ -298,7 +382,7 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
     for i, c in enumerate(conts):
         if c is None:
             continue
-        sp = c.stream_payloads() if isinstance(c, PNGFile) else [(c.name, c.payload)]
+        sp = c.stream_payloads() if isinstance(c, (PNGFile, ZipFile)) else [(c.name, c.payload)]
         for name, pl in sp:
             payloads.append(pl)
             owner.append((i, name))
@@ -308,7 +392,7 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
     for i, c in enumerate(conts):
         if c is None:
             continue
-        n = len(c.stream_payloads()) if isinstance(c, PNGFile) else 1
+        n = len(c.stream_payloads()) if isinstance(c, (PNGFile, ZipFile)) else 1
         lines = ["File type recognised as " + c.file_type]
         total = 0
         ok = True
@@ -322,12 +406,14 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
             if saved > 0:
                 lines.append("%d bits saved in stream %d (%s)" % (saved, j, owner[k + j][1]))
             total += saved
-            pieces.append((batch.output(k + j), batch.checksums(k + j)))
+            pieces.append((batch.output(k + j), None if isinstance(c, ZipFile) else batch.checksums(k + j)))
         if ok:
             if total > 0:
                 lines.append("Total bits saved %d" % total)
                 lines.append("Saved %d bits with optimisation" % total)
-            if isinstance(c, PNGFile):
+            if isinstance(c, ZipFile):   # members keep their CRC-32 (the decoded bytes do not change)
+                results[i] = (c.write([pc[0] for pc in pieces]), lines)
+            elif isinstance(c, PNGFile):
                 zl = [c.streams[j][2].write(pieces[j][0], *pieces[j][1]) for j in range(n)]
                 results[i] = (c.write(zl), lines)
             else:

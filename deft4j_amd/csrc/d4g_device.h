@@ -371,6 +371,9 @@ struct D4GWaveHeap {
     }
 };
 
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+__device__ unsigned long long d4g_dbg_counters[8];   // profile builds: [0] wave trees built, [1] of them through the serial limiter, [2] leaves
+#endif
 // All 64 lanes of one wave call this with the same arguments.  NREG = ceil(MAXN / 64).
 template <int NREG, typename H, typename I, int MAXN, int IDB_, bool OVL, typename FreqFn, typename OutFn>
 __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSymbols, int limit, FreqFn freq, OutFn outLen) {
@@ -493,6 +496,14 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
         maxDepth = d > maxDepth ? d : maxDepth;
     }
     maxDepth = wave_max_i32(maxDepth);
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    if (lane == 0) {
+        int slot = MAXN > 100 ? 0 : (MAXN > 20 ? 3 : 5);   // literal/length, distance, code-length trees
+        atomicAdd(&d4g_dbg_counters[slot], 1ULL);
+        if (maxDepth > limit) atomicAdd(&d4g_dbg_counters[slot + 1], 1ULL);
+        if (slot == 0) atomicAdd(&d4g_dbg_counters[2], (unsigned long long)nl);
+    }
+#endif
     if (maxDepth > limit) {
         int err = 0;
         if (lane == 0) err = d4g_tree_finish(m, 1, 0, nl, root, numSymbols, limit, outLen);
