@@ -23,6 +23,7 @@ D4G_DEV int ld_state_i32(const int32_t* p) { return (int)ld_sc1((const uint32_t*
 
 
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+__device__ unsigned long long d4g_dbg_hdr[4];   // profile builds: header rewrite sections (RLE, code-length tree, tail), count
 // profile builds: a clock read that is not overtaken by (and does not overtake) outstanding LDS / memory operations
 D4G_DEV long long d4g_clock_drained() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -497,6 +498,23 @@ __device__ void t0_remove_trailing_header_codes(D4GState* S) {
     S->hdrBits -= saved;
 }
 
+// removeTrailingHeaderCodes by all lanes of wave 0: trim_codelens drops trailing zero lengths (in code-length
+// order) one at a time while a non-zero one exists, i.e. it keeps everything up to the last non-zero length.
+__device__ void w0_remove_trailing_header_codes(D4GState* S) {
+    if (S->type != D4G_DYNAMIC) return;
+    const int lane = threadIdx.x & 63;
+    const int nCl = S->nCl;
+    bool nz = lane < nCl && lane < 19 && S->clLen[D4G_CL_ORDER[lane]] != 0;
+    unsigned long long m = __ballot(nz);
+    int n = m ? 64 - __clzll((long long)m) : nCl;
+    if (lane == 0) {
+        long long saved = 3LL * (nCl - n);
+        S->nCl = n;
+        S->sizeBits -= saved;
+        S->hdrBits -= saved;
+    }
+}
+
 // rewriteHeader — DeflateBlockHuffman.java:484-577 (HuffmanTable.packCodeLengths :100-186 inside).  All threads.
 // Wave 0 finds the runs of the concatenated code lengths with ballots; the lane at each run start packs
 // that run (the pair count first, then the pairs at their prefix-summed position).  Thread 0 finishes with
@@ -504,6 +522,9 @@ __device__ void t0_remove_trailing_header_codes(D4GState* S) {
 __device__ void wg_rewrite_header(D4GLds* L, int flags) {
     D4GState* S = &L->st;
     __syncthreads();
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    long long r0 = d4g_clock_drained(), r1 = 0, r2 = 0;
+#endif
     if (S->type != D4G_DYNAMIC) return;
     if (threadIdx.x < 20) L->clFreq[threadIdx.x] = 0;
     __syncthreads();
@@ -552,17 +573,32 @@ __device__ void wg_rewrite_header(D4GLds* L, int flags) {
             base += __shfl(incl, 63);
         }
         if (lane == 0) S->nPairs = base;
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+        r1 = d4g_clock_drained();
+#endif
         // code-length code (Huffman.ofRLEPacked, B/huffman/Huffman.java:117-134) and the header's size
         w0_build_cl_tree(L);
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+        r2 = d4g_clock_drained();
+#endif
         int hbl = 0;
         if (lane < 19) hbl = (int)L->clFreq[lane] * (S->clLen[lane] + (lane >= 16 ? pair_extra_bits(lane) : 0));
-        long long hb = 5 + 5 + 4 + 19 * 3 + wave_sum_i64(hbl);
+        long long hb = 5 + 5 + 4 + 19 * 3 + wave_sum_i32(hbl);
         if (lane == 0) {
             S->sizeBits += hb - S->hdrBits;
             S->hdrBits = hb;
             S->nCl = 19;
-            t0_remove_trailing_header_codes(S);
         }
+        d4g_wave_sync();
+        w0_remove_trailing_header_codes(S);
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+        if (lane == 0) {
+            atomicAdd(&d4g_dbg_hdr[0], (unsigned long long)(r1 - r0));
+            atomicAdd(&d4g_dbg_hdr[1], (unsigned long long)(r2 - r1));
+            atomicAdd(&d4g_dbg_hdr[2], (unsigned long long)(d4g_clock_drained() - r2));
+            atomicAdd(&d4g_dbg_hdr[3], 1ULL);
+        }
+#endif
     }
     __syncthreads();
 }
@@ -623,7 +659,7 @@ __device__ void wg_recode_header(D4GLds* L) {
 // optimiseHeader — DeflateBlockHuffman.java:471-476
 __device__ void wg_optimise_header(D4GLds* L) {
     __syncthreads();
-    if (threadIdx.x == 0) t0_remove_trailing_header_codes(&L->st);
+    if (threadIdx.x < 64) w0_remove_trailing_header_codes(&L->st);
     __syncthreads();
     wg_replace_rle_runs(L, false);
 }

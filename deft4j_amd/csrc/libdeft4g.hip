@@ -283,6 +283,7 @@ int d4g_debug_opstats(long long* out64) {
     std::lock_guard<std::mutex> lk(g_mu);
     rt_d2h(out64, engine().dOpStats, 64 * 8);
     (void)hipMemcpyFromSymbol(out64 + 56, HIP_SYMBOL(d4g_dbg_counters), 7 * 8);
+    (void)hipMemcpyFromSymbol(out64 + 28, HIP_SYMBOL(d4g_dbg_hdr), 4 * 8);
     return 0;
 }
 #endif
