@@ -372,6 +372,7 @@ struct D4GWaveHeap {
 };
 
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+__device__ unsigned long long d4g_dbg_tree[4];       // literal/length tree sections: leaves, merges, depths
 __device__ unsigned long long d4g_dbg_counters[8];   // profile builds: [0] wave trees built, [1] of them through the serial limiter, [2] leaves
 #endif
 // All 64 lanes of one wave call this with the same arguments.  NREG = ceil(MAXN / 64).
@@ -410,16 +411,21 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
             // levels whose children are both register slots: no region checks, the child's id is read only once chosen
             const int regHalf = half < 31 ? half : 31;   // k < 31  =>  2k + 2 < 64
             bool placed = false;
-            while (k < regHalf) {
-                int child = 2 * k + 1;
-                unsigned cw = hp.regW(child);
-                if (child + 1 < s) {
-                    unsigned rw2 = hp.regW(child + 1);
-                    if (cw > rw2) { cw = rw2; child = child + 1; }
+            if (regHalf > 0) {
+                // every lane k picks the child its slot would hand up (left unless left > right), once for the whole
+                // path: the slots below the moving position are not touched until the walk reaches them
+                const int li = 2 * lane + 1;
+                const unsigned lwv = (unsigned)__shfl(hp.w0, li & 63), rwv = (unsigned)__shfl(hp.w0, (li + 1) & 63);
+                const bool right = li + 1 < s && lwv > rwv;
+                const int cidx = right ? li + 1 : li;
+                const int cwv = (int)(right ? rwv : lwv);
+                while (k < regHalf) {
+                    int child = d4g_readlane(cidx, k);
+                    unsigned cw = (unsigned)d4g_readlane(cwv, k);
+                    if (xw <= cw) { placed = true; break; }
+                    hp.regPut(k, cw, hp.regI(child));
+                    k = child;
                 }
-                if (xw <= cw) { placed = true; break; }
-                hp.regPut(k, cw, hp.regI(child));
-                k = child;
             }
             if (!placed) {
                 while (k < half) {   // the rest of the path (slots in LDS)
@@ -439,6 +445,9 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
             hp.put(k, xw, xi);
         }
     };
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    long long tq0 = clock64();
+#endif
     // leaves in symbol order: 64 frequencies per step, the used ones are offered one by one
     for (int base = 0; base < numSymbols; base += 64) {
         int i = base + lane;
@@ -464,6 +473,9 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
         }
         index++;
     }
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    long long tq1 = clock64();
+#endif
     int nn = nl;
     for (int i = 0; i < nl - 1; i++) {
         unsigned lw, rw;
@@ -482,6 +494,13 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
     unsigned rootW;
     int root;
     pq_remove(rootW, root);
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    long long tq2 = clock64();
+    if (lane == 0 && MAXN > 100) {
+        atomicAdd(&d4g_dbg_tree[0], (unsigned long long)(tq1 - tq0));
+        atomicAdd(&d4g_dbg_tree[1], (unsigned long long)(tq2 - tq1));
+    }
+#endif
     // leaf depths: one lane per leaf walks to the root
     int dep[NREG];
     int maxDepth = 0;
@@ -497,6 +516,7 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
     }
     maxDepth = wave_max_i32(maxDepth);
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    if (lane == 0 && MAXN > 100) atomicAdd(&d4g_dbg_tree[2], (unsigned long long)(clock64() - tq2));
     if (lane == 0) {
         int slot = MAXN > 100 ? 0 : (MAXN > 20 ? 3 : 5);   // literal/length, distance, code-length trees
         atomicAdd(&d4g_dbg_counters[slot], 1ULL);

@@ -33,6 +33,13 @@ D4G_DEV long long d4g_clock_drained() {
 }
 #endif
 
+// occupancy target of a kernel (caps its VGPR budget); the emulator build has no such notion
+#ifdef D4G_HOSTSIM
+#define D4G_WAVES_PER_SIMD(n)
+#else
+#define D4G_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, 8)))
+#endif
+
 struct D4GCtx {
     const uint2* tok;         // {token word, decoded-byte offset}
     const uint2* refs;        // back-reference records {packed symbols/length, decoded-byte offset}
@@ -164,7 +171,7 @@ D4G_DEV void lw_step(D4GLitWalk& w, const uint32_t* Uw, const uint16_t* lc) {
 // The histogram follows the token list (back-reference symbols out, literal bytes in).
 // ---------------------------------------------------------------------------------------
 #define D4G_TOK_ILP 2  // records per lane per step: independent chains hide LDS / L2 latency
-__device__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
+__device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
                                     bool prune) {
     D4GState* S = &L->st;
     const int K = D4G_TOK_ILP;
@@ -331,7 +338,7 @@ D4G_DEV void wave_for_selected(int wave, int nw, int nWords, int nRef, const uin
     }
 }
 
-__device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut, int mode) {
+__device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut, int mode) {
     D4GState* S = &L->st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int* binSize = L->misc;        // [32]
@@ -461,7 +468,7 @@ __device__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const ui
 // Header operations on the LDS state
 // ---------------------------------------------------------------------------------------
 // code-length-code tree from L->clFreq — Huffman.ofRLEPacked, B/huffman/Huffman.java:117-134
-__device__ void t0_build_cl_tree(D4GLds* L) {
+__device__ __forceinline__ void t0_build_cl_tree(D4GLds* L) {
     D4GState* S = &L->st;
     TreeMem<uint32_t, uint8_t, 20> tm;
     tm.carve(L->treeCl, 1);
@@ -472,7 +479,7 @@ __device__ void t0_build_cl_tree(D4GLds* L) {
 }
 
 // the same by all lanes of wave 0
-__device__ void w0_build_cl_tree(D4GLds* L) {
+__device__ __forceinline__ void w0_build_cl_tree(D4GLds* L) {
     D4GState* S = &L->st;
 #if !defined(D4G_HOSTSIM) || defined(D4G_SIM_WAVE_HEAP)
     TreeMem<uint32_t, uint8_t, 20> tm;
@@ -489,7 +496,7 @@ __device__ void w0_build_cl_tree(D4GLds* L) {
 }
 
 // removeTrailingHeaderCodes — DeflateBlockHuffman.java:366-370 (thread 0)
-__device__ void t0_remove_trailing_header_codes(D4GState* S) {
+__device__ __forceinline__ void t0_remove_trailing_header_codes(D4GState* S) {
     if (S->type != D4G_DYNAMIC) return;
     int n = trim_codelens(S->nCl, [&](int s) { return (int)S->clLen[s]; });
     long long saved = 3LL * (S->nCl - n);
@@ -500,7 +507,7 @@ __device__ void t0_remove_trailing_header_codes(D4GState* S) {
 
 // removeTrailingHeaderCodes by all lanes of wave 0: trim_codelens drops trailing zero lengths (in code-length
 // order) one at a time while a non-zero one exists, i.e. it keeps everything up to the last non-zero length.
-__device__ void w0_remove_trailing_header_codes(D4GState* S) {
+__device__ __forceinline__ void w0_remove_trailing_header_codes(D4GState* S) {
     if (S->type != D4G_DYNAMIC) return;
     const int lane = threadIdx.x & 63;
     const int nCl = S->nCl;
@@ -519,7 +526,8 @@ __device__ void w0_remove_trailing_header_codes(D4GState* S) {
 // Wave 0 finds the runs of the concatenated code lengths with ballots; the lane at each run start packs
 // that run (the pair count first, then the pairs at their prefix-summed position).  Thread 0 finishes with
 // the code-length code and the header size.
-__device__ void wg_rewrite_header(D4GLds* L, int flags) {
+// (forced inline: inside a kernel the compiler then knows L is LDS and drops the generic-pointer checks)
+__device__ __forceinline__ void wg_rewrite_header(D4GLds* L, int flags) {
     D4GState* S = &L->st;
     __syncthreads();
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
@@ -604,7 +612,7 @@ __device__ void wg_rewrite_header(D4GLds* L, int flags) {
 }
 
 // replaceRLERunsWithLiteralsIfSmaller — DeflateBlockHuffman.java:321-332.  All threads.
-__device__ void wg_replace_rle_runs(D4GLds* L, bool prune) {
+__device__ __forceinline__ void wg_replace_rle_runs(D4GLds* L, bool prune) {
     D4GState* S = &L->st;
     long long saved = 0;
     __syncthreads();
@@ -625,7 +633,7 @@ __device__ void wg_replace_rle_runs(D4GLds* L, bool prune) {
 }
 
 // recodeHeader — DeflateBlockHuffman.java:579-629 (numCodelenLens deliberately not reset)
-__device__ void wg_recode_header(D4GLds* L) {
+__device__ __forceinline__ void wg_recode_header(D4GLds* L) {
     D4GState* S = &L->st;
     __syncthreads();
     if (S->type != D4G_DYNAMIC) return;
@@ -657,7 +665,7 @@ __device__ void wg_recode_header(D4GLds* L) {
 }
 
 // optimiseHeader — DeflateBlockHuffman.java:471-476
-__device__ void wg_optimise_header(D4GLds* L) {
+__device__ __forceinline__ void wg_optimise_header(D4GLds* L) {
     __syncthreads();
     if (threadIdx.x < 64) w0_remove_trailing_header_codes(&L->st);
     __syncthreads();
@@ -665,7 +673,7 @@ __device__ void wg_optimise_header(D4GLds* L) {
 }
 
 // Σ token bits from the histogram — recodeToHuffmanInternal, DeflateBlockHuffman.java:759-770
-__device__ void wg_litlen_bits_from_hist(D4GLds* L) {
+__device__ __forceinline__ void wg_litlen_bits_from_hist(D4GLds* L) {
     D4GState* S = &L->st;
     long long v = 0;
     __syncthreads();
@@ -686,7 +694,8 @@ __device__ void wg_litlen_bits_from_hist(D4GLds* L) {
 }
 
 // recodeHuffman — DeflateBlockHuffman.java:670-743 + recodeToHuffman :745-757
-__device__ void wg_recode_huffman(D4GLds* L, long long* prof = nullptr) {
+// (forced inline: inside a kernel the compiler then knows L is LDS and drops the generic-pointer checks)
+__device__ __forceinline__ void wg_recode_huffman(D4GLds* L, long long* prof = nullptr) {
     D4GState* S = &L->st;
     __syncthreads();
 #ifdef D4G_PROFILE_OPS
@@ -786,7 +795,7 @@ __device__ void wg_recode_huffman(D4GLds* L, long long* prof = nullptr) {
 }
 
 // recodeToFixedHuffman — DeflateBlockHuffman.java:637-653
-__device__ void wg_recode_to_fixed(D4GLds* L) {
+__device__ __forceinline__ void wg_recode_to_fixed(D4GLds* L) {
     D4GState* S = &L->st;
     __syncthreads();
     if (S->type == D4G_FIXED) return;
@@ -899,7 +908,7 @@ __device__ void wg_publish_slot(const D4GCtx& c, const D4GQueue& q, int blk, int
 // ---------------------------------------------------------------------------------------
 // State-op executor: one workgroup = one op of the program on one block.
 // ---------------------------------------------------------------------------------------
-__device__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId) {
+__device__ __forceinline__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, int blk, int opId) {
     const D4GOp op = c.ops[opId];
 #ifdef D4G_PROFILE_OPS
     long long tStart = clock64();
@@ -1036,7 +1045,7 @@ D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int& blkSlot, int& opRel) {
     return blkSlot < nActive;
 }
 
-__global__ void __launch_bounds__(256) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(7) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
     __shared__ D4GLds L;
     int bs, orel;
     if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;

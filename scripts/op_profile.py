@@ -35,6 +35,8 @@ if buf[54]:
     print("hdr search: mean flag-dependent runs per op %.1f" % (buf[55] / buf[54]))
 if buf[31]:
     print("header rewrite (mean cycles): runs+pairs %.0f  code-length tree %.0f  tail %.0f  (n=%d)" % (buf[28] / buf[31], buf[29] / buf[31], buf[30] / buf[31], buf[31]))
+if buf[56]:
+    print("lit tree (mean cycles): leaves %.0f  merges %.0f  depths %.0f" % (buf[16] / buf[56], buf[17] / buf[56], buf[18] / buf[56]))
 print("wave trees: lit %d (limiter %d, mean leaves %.1f)  dist %d (limiter %d)  code-length %d (limiter %d)"
       % (buf[56], buf[57], buf[58] / max(1, buf[56]), buf[59], buf[60], buf[61], buf[62]))
 for arg in (0, 1):
