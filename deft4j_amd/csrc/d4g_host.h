@@ -576,8 +576,18 @@ struct Batch {
                 if (nc <= cap) break;
                 cap = nc + 1024;
             }
-            // 2. speculative probes; only the candidates that parse come back
+            // 1b. header pre-filter (one lane per candidate) — 2. speculative probes of the survivors; only the candidates
+            // that parse come back
             stats.scan_candidates = (i64)nc;
+            if (nc) {
+                D4GProbeIn* dKept = (D4GProbeIn*)rt_malloc((size_t)nc * sizeof(D4GProbeIn));
+                rt_memset(dN, 0, 4);
+                RT_LAUNCH(k_prefilter_headers, (nc + 63) / 64, 64, dStreams, dCands, nc, dKept, dN);
+                stats.kernel_launches++;
+                rt_d2h(&nc, dN, 4);
+                rt_free(dCands);
+                dCands = dKept;
+            }
             if (nc) {
                 D4GProbeHit* dHits = (D4GProbeHit*)rt_malloc((size_t)nc * sizeof(D4GProbeHit));
                 rt_memset(dN, 0, 4);

@@ -260,6 +260,122 @@ __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* strea
 }
 
 // ---------------------------------------------------------------------------------------
+// 1b. Header pre-filter.  The scan's candidates are almost all false positives (a plausible prolog and a
+// complete code-length code at a random bit position); the probe would spend a whole wave and ~300 serial symbol
+// decodes on each.  Here one LANE per candidate walks the coded code lengths straight from global memory with a
+// private 128-entry decode table, keeping only the Kraft sums: a candidate survives when its literal/length code is
+// complete with an end-of-block code and its distance code is complete or has at most one code — the conditions
+// the strict probe applies (d4g_parse_block), so nothing the probe would accept is dropped.  Survivors are
+// compacted for the probe.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_prefilter_headers(const D4GStreamDesc* streams, const D4GProbeIn* in, unsigned n, D4GProbeIn* kept,
+                                                          unsigned* nKept) {
+    __shared__ uint8_t lut[64 * 128];   // per lane: 7-bit window -> sym | len << 5
+    const int lane = threadIdx.x & 63;
+    const unsigned idx = blockIdx.x * 64 + lane;
+    bool ok = idx < n;
+    D4GProbeIn pi;
+    pi.stream = 0; pi.strict = 1; pi.bitPos = 0;
+    if (ok) pi = in[idx];
+    const D4GStreamDesc sd = streams[pi.stream];
+    const long long nbits = sd.len * 8;
+    long long pos = pi.bitPos;
+    const uint32_t* words = (const uint32_t*)sd.data;   // 16-byte aligned, readable past len
+    auto peek = [&](long long p) -> uint64_t {          // 57+ valid bits at bit p
+        long long w = p >> 5;
+        int sh = (int)(p & 31);
+        uint64_t lo = words[w] | ((uint64_t)words[w + 1] << 32);
+        uint64_t hi = words[w + 2];
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    };
+    __shared__ uint8_t clens[64 * 20];
+    uint8_t* T = lut + lane * 128;
+    uint8_t* CLN = clens + lane * 20;
+    int nLit = 0, nDist = 0;
+    if (ok) {
+        uint64_t b = peek(pos);
+        nLit = (int)((b >> 3) & 31) + 257;
+        nDist = (int)((b >> 8) & 31) + 1;
+        int nCl = (int)((b >> 13) & 15) + 4;
+        ok = ((b >> 1) & 3) == 2 && nLit <= 286 && nDist <= 30 && pos + 17 + 3 * nCl <= nbits;
+        if (ok) {
+            pos += 17;
+            // 19 x 3 bits = 57 bits: one window.  Counts and next codes per length live in 8-bit fields of a word
+            // (no dynamically indexed register arrays); the lengths themselves in the lane's LDS row.
+            uint64_t c = peek(pos);
+            uint64_t cnt64 = 0;
+            for (int k = 0; k < 19; k++) CLN[k] = 0;
+            for (int i = 0; i < nCl; i++) {
+                int l = (int)((c >> (3 * i)) & 7);
+                CLN[D4G_CL_ORDER[i]] = (uint8_t)l;
+                if (l) cnt64 += 1ULL << (8 * l);
+            }
+            pos += 3 * nCl;
+            // canonical codes (Huffman.buildCodes), LUT over 7 bits (LSB-first windows: codes are bit-reversed)
+            uint64_t next64 = 0;
+            int code = 0;
+            for (int l = 1; l <= 7; l++) {
+                code = (code + (l > 1 ? (int)((cnt64 >> (8 * (l - 1))) & 255) : 0)) << 1;
+                next64 |= (uint64_t)(code & 255) << (8 * l);
+            }
+            for (int e = 0; e < 128; e++) T[e] = 0xff;
+            for (int k = 0; k < 19; k++) {
+                int l = CLN[k];
+                if (l) {
+                    int cd = (int)((next64 >> (8 * l)) & 255);
+                    next64 += 1ULL << (8 * l);
+                    unsigned r = 0;
+                    for (int bI = 0; bI < l; bI++) r |= ((cd >> bI) & 1u) << (l - 1 - bI);
+                    for (unsigned e = r; e < 128; e += (1u << l)) T[e] = (uint8_t)(k | (l << 5));
+                }
+            }
+        }
+    }
+    if (ok) {
+        const int combined = nLit + nDist;
+        long long kraftLit = 0, kraftDist = 0;
+        int i = 0, prev = 0, nDistCodes = 0, eob = 0;
+        while (i < combined) {
+            if (pos + 14 > nbits + 64) { ok = false; break; }
+            uint64_t b = peek(pos);
+            unsigned e = T[b & 127];
+            if (e == 0xff) { ok = false; break; }
+            int sym = e & 31, l = e >> 5;
+            pos += l;
+            b >>= l;
+            int run = 1, value = sym;
+            if (sym == 16) {
+                if (i < 1) { ok = false; break; }
+                run = (int)(b & 3) + 3; pos += 2; value = prev;
+            } else if (sym == 17) {
+                run = (int)(b & 7) + 3; pos += 3; value = 0;
+            } else if (sym == 18) {
+                run = (int)(b & 127) + 11; pos += 7; value = 0;
+            }
+            if (pos > nbits || i + run > combined) { ok = false; break; }
+            if (value) {
+                // the run may span the literal/distance boundary
+                int inLit = i < nLit ? (i + run <= nLit ? run : nLit - i) : 0;
+                kraftLit += (long long)inLit << (15 - value);
+                kraftDist += (long long)(run - inLit) << (15 - value);
+                nDistCodes += run - inLit;
+                if (i <= 256 && i + run > 256) eob = 1;
+            }
+            prev = value;
+            i += run;
+        }
+        ok = ok && kraftLit == (1 << 15) && eob && (kraftDist == (1 << 15) || nDistCodes <= 1);
+    }
+    unsigned long long m = __ballot(ok);
+    if (m) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(nKept, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (ok) kept[base + (unsigned)__popcll(m & ((1ULL << lane) - 1))] = pi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 2./3. Block parser: one wave per block.  EMIT = false probes (counts, end position),
 // EMIT = true writes tokens and the block's initial state.
 // ---------------------------------------------------------------------------------------
