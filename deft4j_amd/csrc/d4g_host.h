@@ -106,6 +106,7 @@ struct Program {
     int nStateFlat = 0, nHdrFlat = 0;
     std::vector<std::pair<size_t, int>> stateOff, hdrOff, wideOff;  // per level: (offset into dLists, count)
     int nRequested = 0;  // ops the plain unrolling would have emitted (for the record)
+    std::set<int> hsCodes;  // distinct code-length sets among the header searches (for the record)
 
     // ---- symbolic identity of a state, used to emit every distinct computation once ----
     // A state is determined by (m, c, h): token mask, code lengths, header — each the result of a
@@ -212,6 +213,7 @@ struct Program {
         const Sym& y = sym[base];
         std::vector<int> key = {y.m, y.c, y.g};
         if (!searched.insert(key).second) return;
+        hsCodes.insert(y.c);
         emit_raw(OP_HDRSEARCH, base, -1, 0, true, false, slotLevel[base] + 1);
     }
 
@@ -385,6 +387,10 @@ struct Engine {  // per-process device objects shared by all batches
         if (ready) return;
         progDyn.build(false);
         progFixed.build(true);
+        if (getenv("D4G_DEBUG_PROGRAM"))
+            fprintf(stderr, "program: %d ops requested, %zu emitted (%zu header searches over %zu distinct code-length sets), %d levels, %d slots, %d masks\n",
+                    progDyn.nRequested, progDyn.ops.size(), (size_t)std::count_if(progDyn.ops.begin(), progDyn.ops.end(), [](const D4GOp& o) { return o.kind == OP_HDRSEARCH; }),
+                    progDyn.hsCodes.size(), progDyn.nLevels, progDyn.nSlots, progDyn.nMasks);
         progDyn.upload();
         progFixed.upload();
         uint8_t tab[128];
@@ -475,6 +481,7 @@ struct Batch {
     uint32_t* dTokRef = nullptr;  // token -> record index
     uint32_t* dBinStat = nullptr; // per block: static bin statistics (d4g_types.h)
     uint64_t* dBinMask = nullptr; // per block: bin record masks
+    D4GHsMemo* dHsMemo = nullptr; // per block: header-search memo
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -493,14 +500,14 @@ struct Batch {
 
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
-        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -791,6 +798,8 @@ struct Batch {
                 dBinMask = (uint64_t*)rt_malloc((size_t)binMaskWords * 8 + 64);
                 rt_memset(dBinStat, 0, nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
                 rt_memset(dBinMask, 0, (size_t)binMaskWords * 8 + 64);
+                dHsMemo = (D4GHsMemo*)rt_malloc(nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
+                rt_memset(dHsMemo, 0, nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
             }
         }
         RtEvent e0, e1;
@@ -1314,6 +1323,7 @@ struct Batch {
         rt_free(dTokRef); dTokRef = nullptr;
         rt_free(dBinStat); dBinStat = nullptr;
         rt_free(dBinMask); dBinMask = nullptr;
+        rt_free(dHsMemo); dHsMemo = nullptr;
         rt_free(dBlocks); dBlocks = nullptr;
         rt_free(dStates); dStates = nullptr;
         rt_free(dMasks); dMasks = nullptr;

@@ -33,6 +33,19 @@ D4G_DEV long long d4g_clock_drained() {
 }
 #endif
 
+// Header-search memo.  The 56 header candidates of a state depend only on its code lengths, and most of a block's
+// ~200 header searches per run see value-identical lengths (a Huffman code hardly moves when a few tokens change):
+// the first search of a length set owns the entry and publishes (header bits, winning candidate); the others reuse it.
+#define D4G_HSMEMO_SLOTS 64
+struct D4GHsMemo {
+    unsigned long long tag;     // first 64-bit hash of the length set, 0 = free
+    unsigned long long check;   // second, independent hash (written by the owner before `state` turns 2)
+    int32_t state;              // 0 free/claimed, 2 published
+    int32_t hdr;                // header bits of the best candidate
+    int32_t lane;               // which candidate
+    int32_t pad;
+};
+
 // occupancy target of a kernel (caps its VGPR budget); the emulator build has no such notion
 #ifdef D4G_HOSTSIM
 #define D4G_WAVES_PER_SIMD(n)
@@ -46,6 +59,7 @@ struct D4GCtx {
     const uint32_t* tokRef;   // token -> back-reference record index
     uint32_t* binStat;        // per block and length symbol: static statistics of its records (d4g_types.h)
     uint64_t* binMask;        // per block and length symbol: which records carry it
+    struct D4GHsMemo* hsMemo; // per block: results of the header searches already done, by code-length set
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -1240,6 +1254,48 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? H.lens[i] : H.lens[D4G_NLIT + i - nLit];
     __syncthreads();
     long long baseLitlenBits = (long long)ld_sc1((const uint64_t*)&base->litlenBits);
+    // ---- memo lookup: two position-keyed 64-bit hashes of the length set ----
+    D4GHsMemo* mine = nullptr;   // the entry this search owns and must publish
+    unsigned long long h1 = 0, h2 = 0;
+    if (c.hsMemo) {
+        for (int i = lane; i < n; i += 64) {
+            unsigned long long w = (unsigned long long)comb[i] + 1;
+            unsigned long long x = w * 0x9e3779b97f4a7c15ULL + (unsigned long long)(i + 1) * 0xbf58476d1ce4e5b9ULL;
+            x ^= x >> 29; x *= 0x94d049bb133111ebULL; x ^= x >> 32;
+            unsigned long long y = (w + 0x632be59bd9b4e019ULL) * ((unsigned long long)(i + 7) * 0xd6e8feb86659fd93ULL | 1ULL);
+            y ^= y >> 31; y *= 0xff51afd7ed558ccdULL; y ^= y >> 33;
+            h1 += x;
+            h2 += y;
+        }
+        h1 = (unsigned long long)wave_sum_i64((long long)h1) + (unsigned long long)nLit * 0x100000001b3ULL;
+        h2 = (unsigned long long)wave_sum_i64((long long)h2) ^ ((unsigned long long)n << 40);
+        if (h1 == 0) h1 = 1;
+        D4GHsMemo* tab = c.hsMemo + (long long)blk * D4G_HSMEMO_SLOTS;
+        long long found = -1;   // >= 0: published result (hdr << 8 | lane)
+        if (lane == 0) {
+            for (int probe = 0; probe < 8; probe++) {
+                D4GHsMemo* e = tab + ((h1 >> 7) + probe) % D4G_HSMEMO_SLOTS;
+                unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
+                if (t == 0) { mine = e; break; }           // ours to compute
+                if (t == h1) {                             // someone has it or is computing it: wait for the result
+                    int st = 0;
+                    for (int spin = 0; spin < (1 << 18); spin++) {
+                        st = d4g_flag_load(&e->state);
+                        if (st == 2) break;
+                        d4g_sleep();
+                    }
+                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2)
+                        found = ((long long)ld_state_i32(&e->hdr) << 8) | (long long)ld_state_i32(&e->lane);
+                    break;                                 // (timeout or a hash clash: compute without the memo)
+                }
+            }
+        }
+        found = __shfl(found, 0);
+        if (found >= 0) {
+            if (lane == 0) *keyp = D4G_MAKE_KEY(baseLitlenBits + (found >> 8), (long long)opId * 64 + (found & 255));
+            return;
+        }
+    }
     // Runs of the combined code lengths, found with ballots.  HuffmanTable.pack turns a run of up to three equal
     // non-zero lengths (up to two zeros) into plain literals whatever the flags: those only add to the symbol
     // counts, once for all 56 candidates.  The other runs are listed for the candidates' own packing (their
@@ -1296,7 +1352,17 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
         key = D4G_MAKE_KEY(size, (long long)opId * 64 + lane);
     }
     key = wave_min_i64(key);
-    if (lane == 0) *keyp = key;
+    if (lane == 0) {
+        *keyp = key;
+        if (mine) {   // publish: result first, then the flag
+            long long bestSize = key >> D4G_KEY_SEQ_BITS;
+            st_sc1((uint32_t*)&mine->hdr, (uint32_t)(int32_t)(bestSize - baseLitlenBits));
+            st_sc1((uint32_t*)&mine->lane, (uint32_t)(key & 63));
+            st_sc1((uint64_t*)&mine->check, (uint64_t)h2);
+            d4g_drain_stores();
+            d4g_flag_store(&mine->state, 2);
+        }
+    }
 #ifdef D4G_PROFILE_OPS
     if (c.opStats && lane == 0) {
         atomicAdd((unsigned long long*)&c.opStats[52], (unsigned long long)(h1 - h0));          // load + runs

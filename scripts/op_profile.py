@@ -44,3 +44,4 @@ for arg in (0, 1):
         cyc, n = buf[k * 2 + arg * 32], buf[k * 2 + 1 + arg * 32]
         if n:
             print("%-9s arg&1=%d  n=%8d  mean %9.0f cycles (%.1f us @2.4GHz)  total %.1f Gcyc" % (nm, arg, n, cyc / n, cyc / n / 2400.0, cyc / 1e9))
+

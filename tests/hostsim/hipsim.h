@@ -97,6 +97,11 @@ inline T __shfl_up(T v, int delta) {
     T o = __shfl(v, lane >= delta ? lane - delta : lane);
     return o;
 }
+inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long expect, unsigned long long v) {
+    unsigned long long o = *p;
+    if (o == expect) *p = v;
+    return o;
+}
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
