@@ -482,6 +482,7 @@ struct Batch {
     uint32_t* dBinStat = nullptr; // per block: static bin statistics (d4g_types.h)
     uint64_t* dBinMask = nullptr; // per block: bin record masks
     D4GHsMemo* dHsMemo = nullptr; // per block: header-search memo
+    D4GRecodeMemo* dRcMemo = nullptr;  // per block: Huffman-rebuild memo
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -500,14 +501,14 @@ struct Batch {
 
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
-        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.rcMemo = dRcMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -800,6 +801,8 @@ struct Batch {
                 rt_memset(dBinMask, 0, (size_t)binMaskWords * 8 + 64);
                 dHsMemo = (D4GHsMemo*)rt_malloc(nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
                 rt_memset(dHsMemo, 0, nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
+                dRcMemo = (D4GRecodeMemo*)rt_malloc(nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
+                rt_memset(dRcMemo, 0, nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
             }
         }
         RtEvent e0, e1;
@@ -1324,6 +1327,7 @@ struct Batch {
         rt_free(dBinStat); dBinStat = nullptr;
         rt_free(dBinMask); dBinMask = nullptr;
         rt_free(dHsMemo); dHsMemo = nullptr;
+        rt_free(dRcMemo); dRcMemo = nullptr;
         rt_free(dBlocks); dBlocks = nullptr;
         rt_free(dStates); dStates = nullptr;
         rt_free(dMasks); dMasks = nullptr;

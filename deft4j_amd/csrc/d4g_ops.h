@@ -20,6 +20,22 @@ D4G_DEV void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC
 D4G_DEV void st_sc1(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 D4G_DEV int ld_state_i32(const int32_t* p) { return (int)ld_sc1((const uint32_t*)p); }
+// flags that hand work from one workgroup to another inside a launch
+#ifdef D4G_HOSTSIM
+D4G_DEV int d4g_flag_load(const int32_t* p) { return *p; }
+D4G_DEV void d4g_flag_store(int32_t* p, int v) { *p = v; }
+D4G_DEV void d4g_release_agent() {}
+D4G_DEV void d4g_acquire_agent() {}
+D4G_DEV void d4g_drain_stores() {}
+D4G_DEV void d4g_sleep() {}
+#else
+D4G_DEV int d4g_flag_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void d4g_flag_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void d4g_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(8); }
+#endif
 
 
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
@@ -46,6 +62,20 @@ struct D4GHsMemo {
     int32_t pad;
 };
 
+// Huffman-rebuild memo.  recodeHuffman's result (both codes, the default header's RLE pairs and code-length code,
+// the bit sizes) is a function of the symbol histogram alone, and many of a block's candidate states share a
+// histogram.  Same protocol as the header-search memo: the first rebuild of a histogram owns the entry and
+// publishes the rebuilt part of the state (bytes [64, 1056): lengths and pairs); later ones copy it.
+#define D4G_RCMEMO_SLOTS 128
+#define D4G_RCMEMO_WORDS 248
+struct D4GRecodeMemo {
+    unsigned long long tag, check;
+    int32_t state, nLit, nDist, nCl, nPairs, err;
+    long long litlenBits, hdrBits;
+    uint32_t body[D4G_RCMEMO_WORDS];
+};
+static_assert(offsetof(D4GState, litLen) == 64 && offsetof(D4GState, hist) == 64 + 4 * D4G_RCMEMO_WORDS, "memo body covers lengths + pairs");
+
 // occupancy target of a kernel (caps its VGPR budget); the emulator build has no such notion
 #ifdef D4G_HOSTSIM
 #define D4G_WAVES_PER_SIMD(n)
@@ -60,6 +90,7 @@ struct D4GCtx {
     uint32_t* binStat;        // per block and length symbol: static statistics of its records (d4g_types.h)
     uint64_t* binMask;        // per block and length symbol: which records carry it
     struct D4GHsMemo* hsMemo; // per block: results of the header searches already done, by code-length set
+    struct D4GRecodeMemo* rcMemo;  // per block: Huffman rebuilds already done, by histogram
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -709,9 +740,67 @@ __device__ __forceinline__ void wg_litlen_bits_from_hist(D4GLds* L) {
 
 // recodeHuffman — DeflateBlockHuffman.java:670-743 + recodeToHuffman :745-757
 // (forced inline: inside a kernel the compiler then knows L is LDS and drops the generic-pointer checks)
-__device__ __forceinline__ void wg_recode_huffman(D4GLds* L, long long* prof = nullptr) {
+__device__ __forceinline__ void wg_recode_huffman(D4GLds* L, D4GRecodeMemo* memoTab, long long* prof = nullptr) {
     D4GState* S = &L->st;
     __syncthreads();
+    // ---- memo lookup by two position-keyed hashes of the histogram ----
+    D4GRecodeMemo* mine = nullptr;
+    unsigned long long h2 = 0;
+    if (memoTab) {
+        unsigned long long a1 = 0, a2 = 0;
+        for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) {
+            unsigned long long w = (unsigned long long)S->hist[i] + 1;
+            unsigned long long x = w * 0x9e3779b97f4a7c15ULL + (unsigned long long)(i + 1) * 0xbf58476d1ce4e5b9ULL;
+            x ^= x >> 29; x *= 0x94d049bb133111ebULL; x ^= x >> 32;
+            unsigned long long y = (w + 0x632be59bd9b4e019ULL) * ((unsigned long long)(i + 7) * 0xd6e8feb86659fd93ULL | 1ULL);
+            y ^= y >> 31; y *= 0xff51afd7ed558ccdULL; y ^= y >> 33;
+            a1 += x;
+            a2 += y;
+        }
+        unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red);
+        h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red);
+        if (h1 == 0) h1 = 1;
+        if (threadIdx.x == 0) {
+            long long role = 0, idx = 0;   // 0 compute without the memo, 1 owner, 2 hit
+            for (int probe = 0; probe < 8; probe++) {
+                int k = (int)(((h1 >> 7) + probe) % D4G_RCMEMO_SLOTS);
+                D4GRecodeMemo* e = memoTab + k;
+                unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
+                if (t == 0) { role = 1; idx = k; break; }
+                if (t == h1) {
+                    int st = 0;
+                    for (int spin = 0; spin < (1 << 16); spin++) {
+                        st = d4g_flag_load(&e->state);
+                        if (st == 2) break;
+                        d4g_sleep();
+                    }
+                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) { role = 2; idx = k; }
+                    break;
+                }
+            }
+            L->red[20] = role;
+            L->red[21] = idx;
+        }
+        __syncthreads();
+        const int role = (int)L->red[20];
+        D4GRecodeMemo* e = memoTab + (int)L->red[21];
+        __syncthreads();
+        if (role == 2) {
+            for (int i = threadIdx.x; i < D4G_RCMEMO_WORDS; i += blockDim.x) ((uint32_t*)S)[16 + i] = ld_sc1(&e->body[i]);
+            if (threadIdx.x == 0) {
+                S->type = D4G_DYNAMIC;
+                S->nLit = ld_state_i32(&e->nLit); S->nDist = ld_state_i32(&e->nDist);
+                S->nCl = ld_state_i32(&e->nCl); S->nPairs = ld_state_i32(&e->nPairs);
+                S->litlenBits = (long long)ld_sc1((const uint64_t*)&e->litlenBits);
+                S->hdrBits = (long long)ld_sc1((const uint64_t*)&e->hdrBits);
+                S->sizeBits = S->litlenBits + S->hdrBits;
+                if (ld_state_i32(&e->err)) S->flags |= 0x100;
+            }
+            __syncthreads();
+            return;
+        }
+        if (role == 1) mine = e;
+    }
 #ifdef D4G_PROFILE_OPS
     long long pt0 = clock64(), pt1 = 0, pt2 = 0;
 #endif
@@ -798,6 +887,20 @@ __device__ __forceinline__ void wg_recode_huffman(D4GLds* L, long long* prof = n
 #endif
     wg_litlen_bits_from_hist(L);
     wg_rewrite_header(L, F_DEFAULT);
+    if (mine) {   // publish the rebuilt part of the state, then the flag
+        for (int i = threadIdx.x; i < D4G_RCMEMO_WORDS; i += blockDim.x) st_sc1(&mine->body[i], ((const uint32_t*)S)[16 + i]);
+        if (threadIdx.x == 0) {
+            st_sc1((uint32_t*)&mine->nLit, (uint32_t)S->nLit); st_sc1((uint32_t*)&mine->nDist, (uint32_t)S->nDist);
+            st_sc1((uint32_t*)&mine->nCl, (uint32_t)S->nCl); st_sc1((uint32_t*)&mine->nPairs, (uint32_t)S->nPairs);
+            st_sc1((uint32_t*)&mine->err, (uint32_t)((S->flags & 0x100) ? 1 : 0));
+            st_sc1((uint64_t*)&mine->litlenBits, (uint64_t)S->litlenBits);
+            st_sc1((uint64_t*)&mine->hdrBits, (uint64_t)S->hdrBits);
+            st_sc1((uint64_t*)&mine->check, (uint64_t)h2);
+        }
+        d4g_drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) d4g_flag_store(&mine->state, 2);
+    }
 #ifdef D4G_PROFILE_OPS
     if (threadIdx.x == 0 && prof) {
         atomicAdd((unsigned long long*)&prof[24], (unsigned long long)(pt1 - pt0));          // literal/length tree (thread 0)
@@ -863,21 +966,6 @@ D4G_DEV bool d4g_pull_task(const D4GQueue& q, int& cursor, int& opIdx, int& actI
     return false;
 }
 
-#ifdef D4G_HOSTSIM
-D4G_DEV int d4g_flag_load(const int32_t* p) { return *p; }
-D4G_DEV void d4g_flag_store(int32_t* p, int v) { *p = v; }
-D4G_DEV void d4g_release_agent() {}
-D4G_DEV void d4g_acquire_agent() {}
-D4G_DEV void d4g_drain_stores() {}
-D4G_DEV void d4g_sleep() {}
-#else
-D4G_DEV int d4g_flag_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-D4G_DEV void d4g_flag_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-D4G_DEV void d4g_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-D4G_DEV void d4g_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-D4G_DEV void d4g_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(8); }
-#endif
 
 D4G_DEV void wg_load_state(D4GState* S, const D4GState* g) {
     __syncthreads();
@@ -977,7 +1065,7 @@ __device__ __forceinline__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, in
             wg_replace_backrefs(L, c, b, maskIn, mo, true);
             if (threadIdx.x == 0) S->maskSlot = op.maskSlot;
         }
-        wg_recode_huffman(L, c.opStats);
+        wg_recode_huffman(L, c.rcMemo ? c.rcMemo + (long long)blk * D4G_RCMEMO_SLOTS : nullptr, c.opStats);
         break;
     }
     case OP_RECODE_FULL: {  // recodedHuffmanFull — DeflateStream.java:212-229
@@ -988,7 +1076,7 @@ __device__ __forceinline__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, in
             int ms = op.scratchMask + (it & 1);
             const uint64_t* mi = mask_ptr(c, b, S->maskSlot);
             wg_replace_backrefs(L, c, b, mi, mask_ptr(c, b, ms), true);
-            wg_recode_huffman(L, c.opStats);
+            wg_recode_huffman(L, c.rcMemo ? c.rcMemo + (long long)blk * D4G_RCMEMO_SLOTS : nullptr, c.opStats);
             __syncthreads();
             long long thisSize = S->sizeBits;
             __syncthreads();
