@@ -483,6 +483,7 @@ struct Batch {
     uint64_t* dBinMask = nullptr; // per block: bin record masks
     D4GHsMemo* dHsMemo = nullptr; // per block: header-search memo
     D4GRecodeMemo* dRcMemo = nullptr;  // per block: Huffman-rebuild memo
+    uint64_t* dPassMemo = nullptr;     // per block: token-pass memo entries
     uint8_t* dU = nullptr;
     D4GBlock* dBlocks = nullptr;
     D4GState* dStates = nullptr;
@@ -501,14 +502,14 @@ struct Batch {
 
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
-        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dPassMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.rcMemo = dRcMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.rcMemo = dRcMemo; c.passMemo = dPassMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
@@ -678,7 +679,7 @@ struct Batch {
         int masksAlloc = needSlots ? E.masksPerBlock : 1;
         hBlocks.clear();
         gpuType.clear();
-        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0, binMaskWords = 0;
+        i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0, binMaskWords = 0, passMemoWords = 0;
         std::vector<int32_t> realBlocks;   // device blocks that come straight from the parse (not merge arenas)
         std::vector<D4GStreamDesc> sd(n);
         std::vector<D4GEmitIn> emits;
@@ -702,6 +703,9 @@ struct Batch {
             b.binStat = needSlots ? (i64)hBlocks.size() * D4G_NBINS * D4G_BINSTRIDE : -1;
             b.binMask = binMaskWords;
             if (needSlots) binMaskWords += (i64)D4G_NBINS * maskWordsCap;
+            b.passMemo = needSlots ? passMemoWords : -1;
+            b.passMemoStride = D4G_PASSMEMO_HDR_WORDS + maskWordsCap;
+            if (needSlots) passMemoWords += (i64)D4G_PASSMEMO_SLOTS * b.passMemoStride;
             maskWordsTotal += maskWordsCap * masksAlloc;
             hBlocks.push_back(b);
             gpuType.push_back(type);
@@ -801,6 +805,8 @@ struct Batch {
                 rt_memset(dBinMask, 0, (size_t)binMaskWords * 8 + 64);
                 dHsMemo = (D4GHsMemo*)rt_malloc(nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
                 rt_memset(dHsMemo, 0, nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
+                dPassMemo = (uint64_t*)rt_malloc((size_t)passMemoWords * 8 + 64);
+                rt_memset(dPassMemo, 0, (size_t)passMemoWords * 8 + 64);
                 dRcMemo = (D4GRecodeMemo*)rt_malloc(nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
                 rt_memset(dRcMemo, 0, nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
             }
@@ -1328,6 +1334,7 @@ struct Batch {
         rt_free(dBinMask); dBinMask = nullptr;
         rt_free(dHsMemo); dHsMemo = nullptr;
         rt_free(dRcMemo); dRcMemo = nullptr;
+        rt_free(dPassMemo); dPassMemo = nullptr;
         rt_free(dBlocks); dBlocks = nullptr;
         rt_free(dStates); dStates = nullptr;
         rt_free(dMasks); dMasks = nullptr;

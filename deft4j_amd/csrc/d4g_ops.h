@@ -76,6 +76,20 @@ struct D4GRecodeMemo {
 };
 static_assert(offsetof(D4GState, litLen) == 64 && offsetof(D4GState, hist) == 64 + 4 * D4G_RCMEMO_WORDS, "memo body covers lengths + pairs");
 
+// Token-pass memo.  What replaceBackrefsWithLiteralsIfSmaller does to a state — which records it expands, the
+// histogram changes and the bits saved — depends only on the two codes, the incoming mask and the strict/lenient
+// comparison; many candidate states of a block share all of those.  Entry = header, the 320 histogram deltas, the
+// outgoing mask (memo-owned copy, so entries stay valid across rounds).  Cleared when a merge arena is re-used.
+#define D4G_PASSMEMO_SLOTS 128
+struct D4GPassMemo {
+    unsigned long long tag, check;
+    int32_t state, pad;
+    long long saved;
+    int32_t delta[D4G_HIST];
+    // followed by maskWords u64
+};
+#define D4G_PASSMEMO_HDR_WORDS ((int)(sizeof(D4GPassMemo) / 8))
+
 // occupancy target of a kernel (caps its VGPR budget); the emulator build has no such notion
 #ifdef D4G_HOSTSIM
 #define D4G_WAVES_PER_SIMD(n)
@@ -91,6 +105,7 @@ struct D4GCtx {
     uint64_t* binMask;        // per block and length symbol: which records carry it
     struct D4GHsMemo* hsMemo; // per block: results of the header searches already done, by code-length set
     struct D4GRecodeMemo* rcMemo;  // per block: Huffman rebuilds already done, by histogram
+    uint64_t* passMemo;            // token-pass memo pool (D4GBlock.passMemo / passMemoStride)
     const uint8_t* U;
     const D4GBlock* blocks;
     D4GState* states;     // [numBlocks * slotsPerBlock]
@@ -222,6 +237,76 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
     const int K = D4G_TOK_ILP;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
+    // ---- memo lookup: hashes over both codes, the incoming mask and the comparison mode ----
+    D4GPassMemo* mine = nullptr;
+    unsigned long long h2 = 0;
+    int* histBefore = (int*)L->treeLit;   // (the tree memory is idle during a token pass)
+    if (c.passMemo && b.passMemo >= 0) {
+        auto mix1 = [](unsigned long long i, unsigned long long w) {
+            unsigned long long x = (w + 1) * 0x9e3779b97f4a7c15ULL + (i + 1) * 0xbf58476d1ce4e5b9ULL;
+            x ^= x >> 29; x *= 0x94d049bb133111ebULL; x ^= x >> 32;
+            return x;
+        };
+        auto mix2 = [](unsigned long long i, unsigned long long w) {
+            unsigned long long y = (w + 0x632be59bd9b4e019ULL) * ((i + 7) * 0xd6e8feb86659fd93ULL | 1ULL);
+            y ^= y >> 31; y *= 0xff51afd7ed558ccdULL; y ^= y >> 33;
+            return y;
+        };
+        unsigned long long a1 = 0, a2 = 0;
+        const uint32_t* lw = (const uint32_t*)S->litLen;   // litLen[288] + distLen[32], contiguous
+        for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) { a1 += mix1(i, lw[i]); a2 += mix2(i, lw[i]); }
+        for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) {
+            unsigned long long m = ld_sc1(maskIn + w);
+            a1 += mix1(1000 + w, m);
+            a2 += mix2(1000 + w, m);
+        }
+        unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red) + (prune ? 0x51ed270b35a3ULL : 0);
+        h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red) ^ (prune ? 0x9b05688c2b3e6c1fULL : 0);
+        if (h1 == 0) h1 = 1;
+        uint64_t* pool = c.passMemo + b.passMemo;
+        if (threadIdx.x == 0) {
+            long long role = 0, idx = 0;
+            for (int probe = 0; probe < 8; probe++) {
+                int k = (int)(((h1 >> 7) + probe) % D4G_PASSMEMO_SLOTS);
+                D4GPassMemo* e = (D4GPassMemo*)(pool + (long long)k * b.passMemoStride);
+                unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
+                if (t == 0) { role = 1; idx = k; break; }
+                if (t == h1) {
+                    int st = 0;
+                    for (int spin = 0; spin < (1 << 16); spin++) {
+                        st = d4g_flag_load(&e->state);
+                        if (st == 2) break;
+                        d4g_sleep();
+                    }
+                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) { role = 2; idx = k; }
+                    break;
+                }
+            }
+            L->red[20] = role;
+            L->red[21] = idx;
+        }
+        __syncthreads();
+        const int role = (int)L->red[20];
+        D4GPassMemo* e = (D4GPassMemo*)(pool + L->red[21] * b.passMemoStride);
+        __syncthreads();
+        if (role == 2) {
+            const uint64_t* mm = (const uint64_t*)e + D4G_PASSMEMO_HDR_WORDS;
+            for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(mm + w));
+            for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) S->hist[i] += (uint32_t)ld_state_i32(&e->delta[i]);
+            if (threadIdx.x == 0) {
+                long long saved = (long long)ld_sc1((const uint64_t*)&e->saved);
+                S->sizeBits -= saved;
+                S->litlenBits -= saved;
+            }
+            __syncthreads();
+            return;
+        }
+        if (role == 1) {
+            mine = e;
+            for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) histBefore[i] = (int)S->hist[i];
+            __syncthreads();
+        }
+    }
     wg_fill_lit_cost(L);
     const uint16_t* lc = L->litCost;
     const uint2* rf = c.refs + b.refStart;
@@ -285,12 +370,25 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
                 for_bytes(Ub + rv[j].y, ref_len(a), [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
             }
             uint64_t nm = __ballot(bit[j]);
-            if (lane == 0 && w0 + j < nWords) st_sc1(maskOut + w0 + j, nm);
+            if (lane == 0 && w0 + j < nWords) {
+                st_sc1(maskOut + w0 + j, nm);
+                if (mine) st_sc1((uint64_t*)mine + D4G_PASSMEMO_HDR_WORDS + w0 + j, nm);
+            }
         }
     }
     long long saved = wg_sum_i64((long long)savedLane, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
     __syncthreads();
+    if (mine) {   // publish: histogram deltas, the outgoing mask, then the flag
+        for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) st_sc1((uint32_t*)&mine->delta[i], (uint32_t)((int)S->hist[i] - histBefore[i]));
+        if (threadIdx.x == 0) {
+            st_sc1((uint64_t*)&mine->saved, (uint64_t)saved);
+            st_sc1((uint64_t*)&mine->check, (uint64_t)h2);
+        }
+        d4g_drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) d4g_flag_store(&mine->state, 2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

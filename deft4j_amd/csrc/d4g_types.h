@@ -82,6 +82,8 @@ struct D4GBlock {
     int64_t refCount;
     int64_t binStat;     // first u32 of the block's per-length-symbol statistics (D4G_NBINS x D4G_BINSTRIDE), -1: none
     int64_t binMask;     // first u64 of the block's per-length-symbol record masks (D4G_NBINS x maskWords)
+    int64_t passMemo;    // first u64 of the block's token-pass memo (D4G_PASSMEMO_SLOTS entries), -1: none
+    int64_t passMemoStride;  // u64 words per entry: header + histogram delta + one mask
 };
 
 // Ops of the candidate-search program (one optimiseBlock call = one program run per block).

@@ -239,6 +239,13 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
         }
         mM[w] = v;
     }
+    // the arena block is a new token range: forget the token passes memoised for its previous contents
+    if (c.passMemo && bM.passMemo >= 0)
+        for (int k = threadIdx.x; k < D4G_PASSMEMO_SLOTS; k += blockDim.x) {
+            D4GPassMemo* e = (D4GPassMemo*)(c.passMemo + bM.passMemo + (long long)k * bM.passMemoStride);
+            e->tag = 0;
+            e->state = 0;
+        }
     // static bin statistics and bin masks of the merged block: rows add, masks concatenate like the token masks
     if (bM.binStat >= 0) {
         const uint32_t* gA = c.binStat + bA.binStat;
