@@ -509,7 +509,10 @@ struct Batch {
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
-        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.rcMemo = dRcMemo; c.passMemo = dPassMemo; c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
+        c.tok = dTok; c.refs = dRefs; c.tokRef = dTokRef; c.binStat = dBinStat; c.binMask = dBinMask; c.hsMemo = dHsMemo; c.rcMemo = dRcMemo; c.passMemo = dPassMemo;
+        if (const char* m = getenv("D4G_MEMO")) {   // D4G_MEMO=0: every op computes (the memos are an optimisation only)
+            if (m[0] == '0') { c.hsMemo = nullptr; c.rcMemo = nullptr; c.passMemo = nullptr; }
+        } c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;

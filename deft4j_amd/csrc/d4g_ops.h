@@ -273,15 +273,24 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
                 if (t == 0) { role = 1; idx = k; break; }
                 if (t == h1) {
                     int st = 0;
+#ifdef D4G_PROFILE_OPS
+                    long long w0 = clock64();
+#endif
                     for (int spin = 0; spin < (1 << 16); spin++) {
                         st = d4g_flag_load(&e->state);
                         if (st == 2) break;
                         d4g_sleep();
                     }
+#ifdef D4G_PROFILE_OPS
+                    if (c.opStats) { atomicAdd((unsigned long long*)&c.opStats[32], (unsigned long long)(clock64() - w0)); atomicAdd((unsigned long long*)&c.opStats[33], 1ULL); }
+#endif
                     if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) { role = 2; idx = k; }
                     break;
                 }
             }
+#ifdef D4G_PROFILE_OPS
+            if (c.opStats && role != 2) atomicAdd((unsigned long long*)&c.opStats[19], 1ULL);   // passes actually computed
+#endif
             L->red[20] = role;
             L->red[21] = idx;
         }
@@ -1426,7 +1435,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     long long* keyp = c.keys + (long long)blk * c.nOps + opId;
     int lane = threadIdx.x & 63;
 #ifdef D4G_PROFILE_OPS
-    long long h0 = d4g_clock_drained();
+    long long hs0 = d4g_clock_drained();
 #endif
     __syncthreads();
     if (!ld_state_i32(&base->valid) || ld_state_i32(&base->type) != D4G_DYNAMIC) {
@@ -1530,7 +1539,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     }
     __syncthreads();
 #ifdef D4G_PROFILE_OPS
-    long long h1 = d4g_clock_drained();
+    long long hs1 = d4g_clock_drained();
 #endif
     long long key = D4G_KEY_NONE;
     if (lane < 56) {
@@ -1551,8 +1560,8 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     }
 #ifdef D4G_PROFILE_OPS
     if (c.opStats && lane == 0) {
-        atomicAdd((unsigned long long*)&c.opStats[52], (unsigned long long)(h1 - h0));          // load + runs
-        atomicAdd((unsigned long long*)&c.opStats[53], (unsigned long long)(d4g_clock_drained() - h1));   // candidates (all lanes)
+        atomicAdd((unsigned long long*)&c.opStats[52], (unsigned long long)(hs1 - hs0));          // load + runs
+        atomicAdd((unsigned long long*)&c.opStats[53], (unsigned long long)(d4g_clock_drained() - hs1));   // candidates (all lanes)
         atomicAdd((unsigned long long*)&c.opStats[54], 1ULL);
         atomicAdd((unsigned long long*)&c.opStats[55], (unsigned long long)H.nRuns);
     }

@@ -138,3 +138,20 @@ def test_batch_of_independent_members(D):
     one.close()
     total, outs2 = D.DeflateFilesContainer.optimise(ins[:4], True)
     assert outs2 == outs[:4] and total == sum(saved[:4])
+
+
+def test_memos_change_nothing(D, monkeypatch):
+    """The per-block memos (header search by code-length set, Huffman rebuild by histogram, token pass by codes +
+    mask — matched through two independent 64-bit hashes) only skip repeated work: with D4G_MEMO=0 every op
+    computes, and the outputs must be identical, merge on and off."""
+    ins = [synth.make_stream(3 << 20, 41), synth.make_stream(700000, 42), synth.deflate9(synth.reptext(2 << 20, 43))]
+    for merge in (False, True):
+        outs = []
+        for memo in ("1", "0"):
+            monkeypatch.setenv("D4G_MEMO", memo)
+            b = D.Batch(ins).run(merge)
+            outs.append([(b.result(i)["saved_bits"], b.output(i)) for i in range(len(ins))])
+            b.close()
+        assert outs[0] == outs[1]
+        for i, a in enumerate(ins):
+            assert zlib.decompress(outs[0][i][1], -15) == zlib.decompress(a, -15)
