@@ -33,6 +33,7 @@
 struct SimDim3 { unsigned x, y, z; };
 extern SimDim3 threadIdx, blockIdx, blockDim, gridDim;
 struct uint4 { uint32_t x, y, z, w; };
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 struct uint2 { uint32_t x, y; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 
