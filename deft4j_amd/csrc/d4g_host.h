@@ -32,8 +32,8 @@ static inline int state_block() {
     static int v = 0;
     if (!v) {
         const char* t = getenv("D4G_STATE_BLOCK");  // tuning knob: 64, 128 or 256
-        v = t ? atoi(t) : 128;
-        if (v != 64 && v != 128 && v != 256) v = 128;
+        v = t ? atoi(t) : 256;   // four waves per op: with the memos a level is bound by its longest ops, not by throughput
+        if (v != 64 && v != 128 && v != 256) v = 256;
     }
     return v;
 }
