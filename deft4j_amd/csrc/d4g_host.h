@@ -502,7 +502,7 @@ struct Batch {
 
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
-        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dPassMemo); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dPassMemo); rt_free(chunkPool.batches); rt_free(chunkPool.next); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
@@ -541,10 +541,11 @@ struct Batch {
     }
 
     // ---- parse: header scan -> block probes -> chain -> emit -> pointer jumping ----
-    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits, nRef; };
+    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits, nRef; int firstBatch; };
     struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; };
     std::vector<PStream> ps;
     D4GStreamDesc* dStreams = nullptr;
+    D4GChunkPool chunkPool = {nullptr, nullptr, 0};   // the probe's verified chunk starts, replayed by the emit pass
     uint32_t* dSrc = nullptr;
     int slotsAlloc = 0;
     double msParseKernels = 0;
@@ -603,7 +604,11 @@ struct Batch {
             if (nc) {
                 D4GProbeHit* dHits = (D4GProbeHit*)rt_malloc((size_t)nc * sizeof(D4GProbeHit));
                 rt_memset(dN, 0, 4);
-                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, (D4GProbeOut*)nullptr, nc, dHits, dN);
+                chunkPool.cap = (unsigned)std::min<i64>(1 << 30, totalBytes * 8 / (64 * D4G_CHUNK_BITS) + 2 * (i64)nc + 64);
+                chunkPool.batches = (D4GChunkBatch*)rt_malloc((size_t)chunkPool.cap * sizeof(D4GChunkBatch));
+                chunkPool.next = (unsigned*)rt_malloc(16);
+                rt_memset(chunkPool.next, 0, 16);
+                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, (D4GProbeOut*)nullptr, nc, dHits, dN, chunkPool);
                 stats.kernel_launches++;
                 unsigned nh = 0;
                 rt_d2h(&nh, dN, 4);
@@ -626,10 +631,10 @@ struct Batch {
         std::vector<char> done(n, 0);
         D4GProbeIn* dEx = (D4GProbeIn*)rt_malloc(n * sizeof(D4GProbeIn) + 16);
         D4GProbeOut* dExOut = (D4GProbeOut*)rt_malloc(n * sizeof(D4GProbeOut) + 16);
-        auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o) {
+        auto accept = [&](size_t i, i64 bitPos, const D4GProbeOut& o, bool fromScan) {
             PStream& P = ps[i];
             if (o.status != 0 || o.needHist > upos[i]) { P.status = -1; done[i] = 1; return; }
-            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, (i64)o.nRef});
+            P.blocks.push_back({o.type, o.bfinal, bitPos, o.endBit, o.nTok, o.uLen, o.sizeBits, (i64)o.nRef, fromScan ? o.firstBatch : -1});
             upos[i] += o.uLen;
             P.nTok += o.nTok;
             spos[i] += 3;  // DeflateStream.getSizeBits — :171-182
@@ -651,18 +656,19 @@ struct Batch {
                 while (!done[i]) {
                     auto& v = byStream[i];
                     auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(cur[i], -1));
-                    if (it != v.end() && it->first == cur[i]) accept(i, cur[i], pout[it->second]);
+                    if (it != v.end() && it->first == cur[i]) accept(i, cur[i], pout[it->second], true);
                     else { ex.push_back({(int32_t)i, 0, cur[i]}); exStream.push_back(i); break; }
                 }
             }
             if (ex.empty()) break;
             rt_h2d(dEx, ex.data(), ex.size() * sizeof(D4GProbeIn));
-            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GProbeHit*)nullptr, (unsigned*)nullptr);
+            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GProbeHit*)nullptr, (unsigned*)nullptr,
+                      D4GChunkPool{nullptr, nullptr, 0u});
             stats.kernel_launches++;
             stats.exact_probes += (i64)ex.size();
             std::vector<D4GProbeOut> eo(ex.size());
             rt_d2h(eo.data(), dExOut, ex.size() * sizeof(D4GProbeOut));
-            for (size_t k = 0; k < ex.size(); k++) accept(exStream[k], ex[k].bitPos, eo[k]);
+            for (size_t k = 0; k < ex.size(); k++) accept(exStream[k], ex[k].bitPos, eo[k], false);
         }
         rt_free(dEx); rt_free(dExOut);
         e1.record();
@@ -755,6 +761,7 @@ struct Batch {
                 em.stateIdx = -1;
                 em.sizeBits = pb.sizeBits;
                 em.refStart = hb.refStart;
+                em.firstBatch = pb.firstBatch;
                 if (pb.type != D4G_STORED) {
                     hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.refStart, hb.refCount, hb.uStart, hb.uLen, (hb.refCount + 63) / 64,
                                        pb.type);
@@ -821,7 +828,7 @@ struct Batch {
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
             D4GParseOut po = {dTok, dU, dStates, dRefs, dTokRef};
-            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors);
+            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors, chunkPool);
             stats.kernel_launches++;
             // 4. decoded bytes
             D4GTokRange* dRanges = (D4GTokRange*)rt_malloc(ranges.size() * sizeof(D4GTokRange));
@@ -867,6 +874,8 @@ struct Batch {
         rt_free(dSrc);
         dSrc = nullptr;
         rt_free(dReal);
+        rt_free(chunkPool.batches); rt_free(chunkPool.next);
+        chunkPool = {nullptr, nullptr, 0};
         check_device_errors();
     }
 

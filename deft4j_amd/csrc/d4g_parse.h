@@ -45,8 +45,16 @@ struct D4GProbeOut {
     long long nTok, uLen, sizeBits;
     long long needHist;    // max over back-references of (distance - bytes produced so far in the block)
     int32_t nRef;          // back-reference tokens in the block
-    int32_t pad;
+    int32_t firstBatch;    // first record of the block's verified chunk starts (D4GChunkBatch chain), < 0: none
 };
+// What the probe learned about a batch of 64 chunks, kept for the emit pass: per lane the verified start (bits from
+// the block's first token) and its counts, so the emit decodes every chunk exactly once.
+struct D4GChunkBatch {
+    int32_t next;          // following batch of the same block, -1: last
+    int32_t pad[3];
+    uint4 rec[64];         // .x start, .y tokens | records << 10 | stop flag << 20, .z decoded bytes, .w token bits
+};
+struct D4GChunkPool { D4GChunkBatch* batches; unsigned* next; unsigned cap; };
 struct D4GEmitIn {
     int32_t stream;
     int32_t type;
@@ -57,6 +65,8 @@ struct D4GEmitIn {
     long long stateIdx;    // absolute index into the state pool (slot 0 of the block), -1 for stored
     long long sizeBits;    // from the probe
     long long refStart;    // absolute index of the block's first back-reference record
+    int32_t firstBatch;    // the probe's chunk records for this block (< 0: decode speculatively again)
+    int32_t pad;
 };
 #define D4G_LUT_BITS 10
 #define D4G_INCH 8192
@@ -389,7 +399,7 @@ struct D4GParseOut {
 
 template <bool EMIT>
 __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long long bitPos, int strict, D4GProbeOut& po,
-                                const D4GEmitIn* em, const D4GParseOut& out) {
+                                const D4GEmitIn* em, const D4GParseOut& out, const D4GChunkPool& pool) {
     __shared__ D4GParseLds L;
     int lane = threadIdx.x & 63;
     D4GBitReader br;
@@ -406,7 +416,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         br.inBase = base;
         if (lane == 0) br.reset_to(L.inbuf, bitpos);
     };
-    po.nRef = 0; po.pad = 0;
+    po.nRef = 0; po.firstBatch = -1;
     po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
     stage(bitPos);
     long long pk = 0;
@@ -609,7 +619,16 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         }
         exitp = pos;
     };
+    int recBatch = EMIT ? em->firstBatch : -1;   // emit: next recorded batch; probe: last recorded batch
+    int firstBatch = -1;
+    bool recording = !EMIT && pool.batches != nullptr;
+    const bool replay = EMIT && recBatch >= 0 && pool.batches != nullptr;
     while (true) {
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (replay) {   // the probe's verified starts and counts of this batch
+            rec = pool.batches[recBatch].rec[lane];
+            s0 = tokensStart + (long long)__shfl(rec.x, 0);
+        }
         // the staged input must cover the batch: 64 chunks, one token of overshoot, the 12-byte window of a peek
         {
             long long baseBits = br.inBase * 8;
@@ -625,12 +644,18 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         int exitp = start, need = 0, fl = 0;
         unsigned n = 0, u = 0, r = 0, lb = 0;
         bool dirty = true;
-        for (int pass = 0; pass < 66; pass++) {
-            if (dirty) decode_chunk(std::false_type{}, start, endc, limRel, 0u, 0u, 0u, exitp, n, u, r, lb, need, fl);
-            int pe = __shfl_up(exitp, 1), pfl = __shfl_up(fl, 1);
-            dirty = lane > 0 && pfl == 0 && pe != start;
-            if (dirty) start = pe;
-            if (!__ballot(dirty)) break;
+        if (replay) {
+            start = (int)(tokensStart + (long long)rec.x - baseBits);
+            n = rec.y & 1023u; r = (rec.y >> 10) & 1023u; fl = (int)(rec.y >> 20); u = rec.z; lb = rec.w;
+            need = -0x40000000;   // (the host checked the distances at probe time)
+        } else {
+            for (int pass = 0; pass < 66; pass++) {
+                if (dirty) decode_chunk(std::false_type{}, start, endc, limRel, 0u, 0u, 0u, exitp, n, u, r, lb, need, fl);
+                int pe = __shfl_up(exitp, 1), pfl = __shfl_up(fl, 1);
+                dirty = lane > 0 && pfl == 0 && pe != start;
+                if (dirty) start = pe;
+                if (!__ballot(dirty)) break;
+            }
         }
         // the block ends (or fails) in the first lane that stopped early; lanes up to it hold true tokens
         unsigned long long tm = __ballot(fl != 0);
@@ -651,12 +676,33 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
             unsigned n2, u2, r2, lb2;
             decode_chunk(std::true_type{}, start, endc, limRel, nTok + (sn - pn), nU + (su - pu), nRef + (sr - pr), e2, n2, u2, r2, lb2, need2,
                          fl2);
+            if (replay) exitp = e2;
         }
+        if (recording) {   // leave the verified chunks to the emit pass
+            unsigned idx = 0;
+            if (lane == 0) idx = atomicAdd(pool.next, 1u);
+            idx = __shfl(idx, 0);
+            if (idx < pool.cap) {
+                D4GChunkBatch* bt = pool.batches + idx;
+                bt->rec[lane] = make_uint4((uint32_t)(baseBits + start - tokensStart), n | (r << 10) | ((unsigned)fl << 20), u, lb);
+                if (lane == 0) {
+                    bt->next = -1;
+                    if (recBatch >= 0) pool.batches[recBatch].next = (int32_t)idx;
+                }
+                if (firstBatch < 0) firstBatch = (int)idx;
+                recBatch = (int)idx;
+            } else {
+                recording = false;   // pool exhausted: the emit pass decodes this block speculatively
+                firstBatch = -2;
+            }
+        }
+        if (replay) recBatch = pool.batches[recBatch].next;
         nTok += __shfl(sn, 63);
         nU += __shfl(su, 63);
         nRef += __shfl(sr, 63);
         litlenBits += (unsigned)wave_sum_i32((int)plb);
         if (f < 64) { endBit = baseBits + __shfl(exitp, f); break; }
+        if (replay && recBatch < 0) return;   // (a chain that ends before the block does: cannot happen for a recorded block)
         s0 = baseBits + __shfl(exitp, 63);
         G += 64LL * C;
     }
@@ -675,6 +721,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     po.sizeBits = S->sizeBits;
     po.needHist = (long long)needHist;
     po.nRef = (int32_t)nRef;
+    po.firstBatch = firstBatch == -2 ? -1 : firstBatch;
     if (EMIT) {
         D4GState* g = out.states + em->stateIdx;
         for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
@@ -685,12 +732,12 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
 // false positives; the host reads back a few hundred records instead of all of them).
 struct D4GProbeHit { D4GProbeIn in; D4GProbeOut out; };
 __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
-                                                     D4GProbeHit* hits, unsigned* nHits) {
+                                                     D4GProbeHit* hits, unsigned* nHits, D4GChunkPool pool) {
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
     D4GParseOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none);
+    d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none, pool);
     if ((threadIdx.x & 63) == 0) {
         if (hits) {
             if (po.status == 0) {
@@ -706,10 +753,11 @@ __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* stream
 
 // Emit: one wave per block decodes it again, now writing tokens, back-reference records, the block's
 // initial state (stored blocks: their bytes).
-__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors) {
+__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors,
+                                                    D4GChunkPool pool) {
     const D4GEmitIn em = in[blockIdx.x];
     D4GProbeOut po;
-    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out);
+    d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, pool);
     if ((threadIdx.x & 63) == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
 }
 
