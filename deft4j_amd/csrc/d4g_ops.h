@@ -784,34 +784,45 @@ __device__ __forceinline__ void wg_replace_rle_runs(D4GLds* L, bool prune) {
     __syncthreads();
 }
 
-// recodeHeader — DeflateBlockHuffman.java:579-629 (numCodelenLens deliberately not reset)
+// recodeHeader — DeflateBlockHuffman.java:579-629 (numCodelenLens deliberately not reset).  Wave 0: the pairs are
+// counted and priced 64 at a time, the code-length tree is built by the wave.
 __device__ __forceinline__ void wg_recode_header(D4GLds* L) {
     D4GState* S = &L->st;
     __syncthreads();
     if (S->type != D4G_DYNAMIC) return;
     if (threadIdx.x < 20) L->clFreq[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < S->nPairs; i++) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int np = S->nPairs;
+        for (int i = lane; i < np; i += 64) {
             int sym, run, value;
             uint16_t p = S->pairs[i];
             pair_decode(p, sym, run, value);
-            if (p & D4G_PAIR_EXPANDED) L->clFreq[value] += run;
-            else L->clFreq[sym]++;
+            if (p & D4G_PAIR_EXPANDED) atomicAdd(&L->clFreq[value], (unsigned)run);
+            else atomicAdd(&L->clFreq[sym], 1u);
         }
-        S->sizeBits -= S->hdrBits;
-        t0_build_cl_tree(L);
-        S->nCl = trim_codelens(S->nCl, [&](int s) { return (int)S->clLen[s]; });
-        long long hb = 5 + 5 + 4 + 3LL * S->nCl;
-        for (int i = 0; i < S->nPairs; i++) {
+        d4g_wave_sync();
+        w0_build_cl_tree(L);
+        // trim from the current count (trim_codelens: keep everything up to the last non-zero length)
+        const int nCl0 = S->nCl;
+        bool nz = lane < nCl0 && lane < 19 && S->clLen[D4G_CL_ORDER[lane]] != 0;
+        unsigned long long m = __ballot(nz);
+        const int nCl = m ? 64 - __clzll((long long)m) : nCl0;
+        int hbl = 0;
+        for (int i = lane; i < np; i += 64) {
             int sym, run, value;
             uint16_t p = S->pairs[i];
             pair_decode(p, sym, run, value);
-            if (p & D4G_PAIR_EXPANDED) hb += (long long)run * S->clLen[value];
-            else hb += S->clLen[sym] + (sym >= 16 ? pair_extra_bits(sym) : 0);
+            if (p & D4G_PAIR_EXPANDED) hbl += run * S->clLen[value];
+            else hbl += S->clLen[sym] + (sym >= 16 ? pair_extra_bits(sym) : 0);
         }
-        S->hdrBits = hb;
-        S->sizeBits += hb;
+        long long hb = 5 + 5 + 4 + 3LL * nCl + wave_sum_i32(hbl);
+        if (lane == 0) {
+            S->nCl = nCl;
+            S->sizeBits += hb - S->hdrBits;
+            S->hdrBits = hb;
+        }
     }
     __syncthreads();
 }
