@@ -222,6 +222,87 @@ D4G_DEV void lw_step(D4GLitWalk& w, const uint32_t* Uw, const uint16_t* lc) {
     w.rem = n - 4;
 }
 
+// Token-pass memo, shared by the replace pass and the least-expensive pass.  `kind` separates the functions that are
+// memoised (0 / 1: replace, lenient / strict; 2 / 3: least-expensive, modes 0 / 1).  Returns 0: compute without the
+// memo, 1: this workgroup owns `entry` and must publish it, 2: `entry` holds the result.
+__device__ __forceinline__ int wg_passmemo_lookup(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, int kind,
+                                                  D4GPassMemo*& entry, unsigned long long& h2out) {
+    D4GState* S = &L->st;
+    entry = nullptr;
+    if (!c.passMemo || b.passMemo < 0) return 0;
+    auto mix1 = [](unsigned long long i, unsigned long long w) {
+        unsigned long long x = (w + 1) * 0x9e3779b97f4a7c15ULL + (i + 1) * 0xbf58476d1ce4e5b9ULL;
+        x ^= x >> 29; x *= 0x94d049bb133111ebULL; x ^= x >> 32;
+        return x;
+    };
+    auto mix2 = [](unsigned long long i, unsigned long long w) {
+        unsigned long long y = (w + 0x632be59bd9b4e019ULL) * ((i + 7) * 0xd6e8feb86659fd93ULL | 1ULL);
+        y ^= y >> 31; y *= 0xff51afd7ed558ccdULL; y ^= y >> 33;
+        return y;
+    };
+    unsigned long long a1 = 0, a2 = 0;
+    const uint32_t* lw = (const uint32_t*)S->litLen;   // litLen[288] + distLen[32], contiguous
+    for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) { a1 += mix1(i, lw[i]); a2 += mix2(i, lw[i]); }
+    for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) {
+        unsigned long long m = ld_sc1(maskIn + w);
+        a1 += mix1(1000 + w, m);
+        a2 += mix2(1000 + w, m);
+    }
+    unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red) + (unsigned long long)kind * 0x51ed270b35a3ULL;
+    const unsigned long long h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red) ^ ((unsigned long long)kind * 0x9b05688c2b3e6c1fULL);
+    h2out = h2;
+    if (h1 == 0) h1 = 1;
+    uint64_t* pool = c.passMemo + b.passMemo;
+    if (threadIdx.x == 0) {
+        long long role = 0, idx = 0;
+        for (int probe = 0; probe < 8; probe++) {
+            int k = (int)(((h1 >> 7) + probe) % D4G_PASSMEMO_SLOTS);
+            D4GPassMemo* e = (D4GPassMemo*)(pool + (long long)k * b.passMemoStride);
+            unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
+            if (t == 0) { role = 1; idx = k; break; }
+            if (t == h1) {
+                int st = 0;
+#ifdef D4G_PROFILE_OPS
+                long long w0 = clock64();
+#endif
+                for (int spin = 0; spin < (1 << 16); spin++) {
+                    st = d4g_flag_load(&e->state);
+                    if (st == 2) break;
+                    d4g_sleep();
+                }
+#ifdef D4G_PROFILE_OPS
+                if (c.opStats) { atomicAdd((unsigned long long*)&c.opStats[32], (unsigned long long)(clock64() - w0)); atomicAdd((unsigned long long*)&c.opStats[33], 1ULL); }
+#endif
+                if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) { role = 2; idx = k; }
+                break;
+            }
+        }
+#ifdef D4G_PROFILE_OPS
+        if (c.opStats && role != 2) atomicAdd((unsigned long long*)&c.opStats[19], 1ULL);   // passes actually computed
+#endif
+        L->red[20] = role;
+        L->red[21] = idx;
+    }
+    __syncthreads();
+    const int role = (int)L->red[20];
+    entry = (D4GPassMemo*)(pool + L->red[21] * b.passMemoStride);
+    __syncthreads();
+    return role;
+}
+// a published entry applied to the state in LDS: outgoing mask, histogram deltas, bits saved
+__device__ __forceinline__ void wg_passmemo_apply(D4GLds* L, const D4GBlock& b, const D4GPassMemo* e, uint64_t* maskOut) {
+    D4GState* S = &L->st;
+    const uint64_t* mm = (const uint64_t*)e + D4G_PASSMEMO_HDR_WORDS;
+    for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(mm + w));
+    for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) S->hist[i] += (uint32_t)ld_state_i32(&e->delta[i]);
+    if (threadIdx.x == 0) {
+        long long saved = (long long)ld_sc1((const uint64_t*)&e->saved);
+        S->sizeBits -= saved;
+        S->litlenBits -= saved;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------
 // replaceBackrefsWithLiteralsIfSmaller — DeflateBlockHuffman.java:312-319 over :222-296.
 // One lane per back-reference record, 64 per wave step; the new mask word is the wave ballot.
@@ -241,79 +322,14 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
     D4GPassMemo* mine = nullptr;
     unsigned long long h2 = 0;
     int* histBefore = (int*)L->treeLit;   // (the tree memory is idle during a token pass)
-    if (c.passMemo && b.passMemo >= 0) {
-        auto mix1 = [](unsigned long long i, unsigned long long w) {
-            unsigned long long x = (w + 1) * 0x9e3779b97f4a7c15ULL + (i + 1) * 0xbf58476d1ce4e5b9ULL;
-            x ^= x >> 29; x *= 0x94d049bb133111ebULL; x ^= x >> 32;
-            return x;
-        };
-        auto mix2 = [](unsigned long long i, unsigned long long w) {
-            unsigned long long y = (w + 0x632be59bd9b4e019ULL) * ((i + 7) * 0xd6e8feb86659fd93ULL | 1ULL);
-            y ^= y >> 31; y *= 0xff51afd7ed558ccdULL; y ^= y >> 33;
-            return y;
-        };
-        unsigned long long a1 = 0, a2 = 0;
-        const uint32_t* lw = (const uint32_t*)S->litLen;   // litLen[288] + distLen[32], contiguous
-        for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) { a1 += mix1(i, lw[i]); a2 += mix2(i, lw[i]); }
-        for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) {
-            unsigned long long m = ld_sc1(maskIn + w);
-            a1 += mix1(1000 + w, m);
-            a2 += mix2(1000 + w, m);
-        }
-        unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red) + (prune ? 0x51ed270b35a3ULL : 0);
-        h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red) ^ (prune ? 0x9b05688c2b3e6c1fULL : 0);
-        if (h1 == 0) h1 = 1;
-        uint64_t* pool = c.passMemo + b.passMemo;
-        if (threadIdx.x == 0) {
-            long long role = 0, idx = 0;
-            for (int probe = 0; probe < 8; probe++) {
-                int k = (int)(((h1 >> 7) + probe) % D4G_PASSMEMO_SLOTS);
-                D4GPassMemo* e = (D4GPassMemo*)(pool + (long long)k * b.passMemoStride);
-                unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
-                if (t == 0) { role = 1; idx = k; break; }
-                if (t == h1) {
-                    int st = 0;
-#ifdef D4G_PROFILE_OPS
-                    long long w0 = clock64();
-#endif
-                    for (int spin = 0; spin < (1 << 16); spin++) {
-                        st = d4g_flag_load(&e->state);
-                        if (st == 2) break;
-                        d4g_sleep();
-                    }
-#ifdef D4G_PROFILE_OPS
-                    if (c.opStats) { atomicAdd((unsigned long long*)&c.opStats[32], (unsigned long long)(clock64() - w0)); atomicAdd((unsigned long long*)&c.opStats[33], 1ULL); }
-#endif
-                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) { role = 2; idx = k; }
-                    break;
-                }
-            }
-#ifdef D4G_PROFILE_OPS
-            if (c.opStats && role != 2) atomicAdd((unsigned long long*)&c.opStats[19], 1ULL);   // passes actually computed
-#endif
-            L->red[20] = role;
-            L->red[21] = idx;
-        }
-        __syncthreads();
-        const int role = (int)L->red[20];
-        D4GPassMemo* e = (D4GPassMemo*)(pool + L->red[21] * b.passMemoStride);
-        __syncthreads();
-        if (role == 2) {
-            const uint64_t* mm = (const uint64_t*)e + D4G_PASSMEMO_HDR_WORDS;
-            for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(mm + w));
-            for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) S->hist[i] += (uint32_t)ld_state_i32(&e->delta[i]);
-            if (threadIdx.x == 0) {
-                long long saved = (long long)ld_sc1((const uint64_t*)&e->saved);
-                S->sizeBits -= saved;
-                S->litlenBits -= saved;
-            }
-            __syncthreads();
-            return;
-        }
+    {
+        const int role = wg_passmemo_lookup(L, c, b, maskIn, prune ? 1 : 0, mine, h2);
+        if (role == 2) { wg_passmemo_apply(L, b, mine, maskOut); return; }
         if (role == 1) {
-            mine = e;
             for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) histBefore[i] = (int)S->hist[i];
             __syncthreads();
+        } else {
+            mine = nullptr;
         }
     }
     wg_fill_lit_cost(L);
@@ -504,6 +520,16 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
     static_assert(sizeof(L->treeLit) >= (32 + 320 + 128 * 8 + 1) * 4, "scratch does not fit the tree memory");
     const int nwq = nw < 8 ? nw : 8;
     __syncthreads();
+    // the whole pass is a function of (codes, mask, mode): shared through the token-pass memo
+    D4GPassMemo* mine = nullptr;
+    unsigned long long memoH2 = 0;
+    {
+        const int role = wg_passmemo_lookup(L, c, b, maskIn, 2 + (mode & 1), mine, memoH2);
+        if (role == 2) { wg_passmemo_apply(L, b, mine, maskOut); return; }
+        if (role != 1) mine = nullptr;
+    }
+    uint64_t* memoMask = mine ? (uint64_t*)mine + D4G_PASSMEMO_HDR_WORDS : nullptr;
+    if (mine) for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) st_sc1((uint32_t*)&mine->delta[i], 0u);
     if (threadIdx.x < 64) L->misc[threadIdx.x] = 0;
     if (threadIdx.x < 32) binZ[threadIdx.x] = 0;
     if (threadIdx.x < 4) flags[threadIdx.x] = 0;
@@ -582,18 +608,39 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
             S->litlenBits += remSize;
         }
         flags[2] = (unsigned)(rem + 1);
+        flags[3] = (unsigned)remSize;
     }
     for (int i = threadIdx.x; i < 320; i += blockDim.x) delta[i] = 0;
     __syncthreads();
     const int rem = (int)flags[2] - 1;
-    if (rem < 0) {
-        for (int w = threadIdx.x; w < nWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(maskIn + w));
+    // publish the pass for the states that share it: the flag goes up once every store has drained
+    auto publish = [&]() D4G_LAMBDA_INLINE {
+        if (!mine) return;
+        if (threadIdx.x == 0) {
+            st_sc1((uint64_t*)&mine->saved, (uint64_t)(-(long long)(int)flags[3]));
+            st_sc1((uint64_t*)&mine->check, (uint64_t)memoH2);
+        }
+        d4g_drain_stores();
         __syncthreads();
+        if (threadIdx.x == 0) d4g_flag_store(&mine->state, 2);
+    };
+    if (rem < 0) {
+        for (int w = threadIdx.x; w < nWords; w += blockDim.x) {
+            uint64_t v = ld_sc1(maskIn + w);
+            st_sc1(maskOut + w, v);
+            if (mine) st_sc1(memoMask + w, v);
+        }
+        __syncthreads();
+        publish();
         return;
     }
     // expand the bin: new mask = old | bin mask; the histogram loses the bin's unexpanded records' symbols and gains their bytes
     const uint64_t* bm = bmask + (long long)rem * nWords;
-    for (int w = threadIdx.x; w < nWords; w += blockDim.x) st_sc1(maskOut + w, ld_sc1(maskIn + w) | bm[w]);
+    for (int w = threadIdx.x; w < nWords; w += blockDim.x) {
+        uint64_t v = ld_sc1(maskIn + w) | bm[w];
+        st_sc1(maskOut + w, v);
+        if (mine) st_sc1(memoMask + w, v);
+    }
     // what the already expanded records of the bin contributed to the static row (they were moved earlier)
     if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ld_sc1(maskIn + w) & bm[w]; },
                       [&](int, uint2 rv) {
@@ -608,12 +655,19 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
         for (int i = threadIdx.x; i <= D4G_BIN_COUNT; i += blockDim.x) {
             int moved = (int)row[i] - delta[i];
             if (!moved) continue;
-            if (i < 256) atomicAdd(&S->hist[i], (unsigned)moved);
-            else if (i < D4G_BIN_COUNT) atomicSub(&S->hist[D4G_NLIT + i - D4G_BIN_DIST], (unsigned)moved);
-            else atomicSub(&S->hist[257 + rem], (unsigned)moved);
+            // (byte values, distance symbols and the bin's length symbol are distinct histogram slots)
+            if (i < 256) { atomicAdd(&S->hist[i], (unsigned)moved); if (mine) st_sc1((uint32_t*)&mine->delta[i], (uint32_t)moved); }
+            else if (i < D4G_BIN_COUNT) {
+                atomicSub(&S->hist[D4G_NLIT + i - D4G_BIN_DIST], (unsigned)moved);
+                if (mine) st_sc1((uint32_t*)&mine->delta[D4G_NLIT + i - D4G_BIN_DIST], (uint32_t)(-moved));
+            } else {
+                atomicSub(&S->hist[257 + rem], (unsigned)moved);
+                if (mine) st_sc1((uint32_t*)&mine->delta[257 + rem], (uint32_t)(-moved));
+            }
         }
     }
     __syncthreads();
+    publish();
 }
 
 // ---------------------------------------------------------------------------------------
