@@ -1311,12 +1311,15 @@ __device__ __forceinline__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, in
 // of one deflate block are given workgroup ids that are equal mod 8 — they re-read the same
 // tokens and decoded bytes.  Speed only; nothing depends on placement.
 D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int& blkSlot, int& opRel) {
+    // op-major: the level's ops are sorted longest first, and every block's long ops should start before anyone's
+    // short ones (the short ones then fill the tail of the launch)
     int g = blockIdx.x;
     int x = g & 7, j = g >> 3;
-    int local = j / nOpsLevel;
-    opRel = j - local * nOpsLevel;
+    int nGroups = (nActive + 7) >> 3;
+    opRel = j / nGroups;
+    int local = j - opRel * nGroups;
     blkSlot = local * 8 + x;
-    return blkSlot < nActive;
+    return blkSlot < nActive && opRel < nOpsLevel;
 }
 
 __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(7) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
