@@ -132,7 +132,9 @@ struct D4GBitReader {
     __device__ bool near_end() const { return rel + 1024 > D4G_INCH; }
 };
 
-#define D4G_CHUNK_BITS 256   // bits per lane and pass of the wave-wide token decoder
+#define D4G_CHUNK_BITS 512   // bits per lane and pass of the wave-wide token decoder
+static_assert(64 * D4G_CHUNK_BITS + 160 <= (D4G_INCH + 16) * 8, "a batch of 64 chunks must fit the staged input window");
+static_assert(D4G_CHUNK_BITS + 48 < 1024, "tokens per chunk must fit the 10-bit field of a chunk record");
 // 64 bits of the staged input starting at bit `posRel` (any lane, any position inside the staged chunk)
 __device__ __forceinline__ uint64_t d4g_peek64(const uint8_t* inbuf, int posRel) {
     int a = (posRel >> 3) & ~3;
