@@ -382,6 +382,9 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
     const int lane = threadIdx.x & 63;
     numSymbols = d4g_uniform(numSymbols);  // tell the compiler what is wave-uniform: the queue code then runs on the scalar unit
     limit = d4g_uniform(limit);
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(3);   // a serial section everyone in the workgroup waits for: issue ahead of the throughput-bound waves
+#endif
     D4GWaveHeap hp;
     hp.w0 = 0; hp.i0 = 0;
     hp.deep = (uint64_t*)m.heap;
@@ -527,6 +530,9 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
     if (maxDepth > limit) {
         int err = 0;
         if (lane == 0) err = d4g_tree_finish(m, 1, 0, nl, root, numSymbols, limit, outLen);
+#ifndef D4G_HOSTSIM
+        __builtin_amdgcn_s_setprio(0);
+#endif
         return __shfl(err, 0);
     }
 #pragma unroll
@@ -537,6 +543,9 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
             if (v < numSymbols) outLen(v, dep[r]);
         }
     }
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return 0;
 }
 

@@ -477,7 +477,7 @@ struct Batch {
     // device
     uint8_t* dIn = nullptr;
     uint2* dTok = nullptr;
-    uint2* dRefs = nullptr;       // back-reference records
+    uint4* dRefs = nullptr;       // back-reference records
     uint32_t* dTokRef = nullptr;  // token -> record index
     uint32_t* dBinStat = nullptr; // per block: static bin statistics (d4g_types.h)
     uint64_t* dBinMask = nullptr; // per block: bin record masks
@@ -789,7 +789,7 @@ struct Batch {
         rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
         if (refTot >= (1LL << 32)) throw std::runtime_error("batch holds 2^32 or more back-references: split it");
         dTok = (uint2*)rt_malloc((size_t)tokTot * 8 + 64);
-        dRefs = (uint2*)rt_malloc((size_t)refTot * 8 + 64);
+        dRefs = (uint4*)rt_malloc((size_t)refTot * 16 + 64);
         dTokRef = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
         dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
         dSrc = (uint32_t*)rt_malloc((size_t)uTot * 4 + 64);

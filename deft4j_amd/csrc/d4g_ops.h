@@ -39,6 +39,7 @@ D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(8); }
 
 
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+__device__ unsigned long long d4g_dbg_pass[4];  // computed replace passes: lookup cycles, loop cycles, count, records
 __device__ unsigned long long d4g_dbg_hdr[4];   // profile builds: header rewrite sections (RLE, code-length tree, tail), count
 // profile builds: a clock read that is not overtaken by (and does not overtake) outstanding LDS / memory operations
 D4G_DEV long long d4g_clock_drained() {
@@ -99,7 +100,7 @@ struct D4GPassMemo {
 
 struct D4GCtx {
     const uint2* tok;         // {token word, decoded-byte offset}
-    const uint2* refs;        // back-reference records {packed symbols/length, decoded-byte offset}
+    uint4* refs;              // back-reference records {packed symbols/length, decoded-byte offset, first eight bytes}
     const uint32_t* tokRef;   // token -> back-reference record index
     uint32_t* binStat;        // per block and length symbol: static statistics of its records (d4g_types.h)
     uint64_t* binMask;        // per block and length symbol: which records carry it
@@ -212,6 +213,41 @@ D4G_DEV void lw_start(D4GLitWalk& w, const uint32_t* Uw, uint32_t off, int len) 
     w.rem = len;
     w.total = 0;
 }
+// The same walk starting from a record: bytes 0-7 come with the record, the words after them are requested at the
+// start, so the first three steps never wait for U.
+struct D4GRecWalk {
+    uint32_t b0, b1;   // bytes 0-3 and 4-7 (from the record)
+    uint32_t widx;     // next word of U to request
+    uint32_t cur, nxt;
+    int sh, step, rem, total;
+};
+D4G_DEV void rw_start(D4GRecWalk& w, const uint32_t* Uw, const uint4& rec, int len) {
+    w.b0 = rec.z;
+    w.b1 = rec.w;
+    w.sh = (int)(rec.y & 3u) * 8;
+    w.widx = (rec.y + 8) >> 2;
+    w.cur = 0u; w.nxt = 0u;
+    if (len > 8) { w.cur = Uw[w.widx]; w.nxt = Uw[w.widx + 1]; }
+    w.widx += 2;
+    w.step = 0;
+    w.rem = len;
+    w.total = 0;
+}
+D4G_DEV void rw_step(D4GRecWalk& w, const uint32_t* Uw, const uint16_t* lc) {
+    uint32_t x;
+    if (w.step == 0) x = w.b0;
+    else if (w.step == 1) x = w.b1;
+    else {
+        x = d4g_alignbit(w.nxt, w.cur, w.sh);
+        w.cur = w.nxt;
+        w.nxt = Uw[w.widx++];
+    }
+    w.step++;
+    int l0 = lc[x & 255u], l1 = lc[(x >> 8) & 255u], l2 = lc[(x >> 16) & 255u], l3 = lc[x >> 24];
+    int n = w.rem;
+    w.total += l0 + (n > 1 ? l1 : 0) + (n > 2 ? l2 : 0) + (n > 3 ? l3 : 0);
+    w.rem = n - 4;
+}
 D4G_DEV void lw_step(D4GLitWalk& w, const uint32_t* Uw, const uint16_t* lc) {
     uint32_t x = d4g_alignbit(w.nxt, w.cur, w.sh);
     w.cur = w.nxt;
@@ -318,6 +354,9 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
     const int K = D4G_TOK_ILP;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    long long pp0 = d4g_clock_drained(), pp1 = 0, pp2 = 0;
+#endif
     // ---- memo lookup: hashes over both codes, the incoming mask and the comparison mode ----
     D4GPassMemo* mine = nullptr;
     unsigned long long h2 = 0;
@@ -332,27 +371,30 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
             mine = nullptr;
         }
     }
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    pp1 = d4g_clock_drained();
+#endif
     wg_fill_lit_cost(L);
     const uint16_t* lc = L->litCost;
-    const uint2* rf = c.refs + b.refStart;
+    const uint4* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     const uint32_t* Uw = (const uint32_t*)Ub;
     const int nWords = (int)b.maskWords, nRef = (int)b.refCount;  // a block's counts fit 31 bits
     int savedLane = 0;
     for (int w0 = wave * K; w0 < nWords; w0 += nw * K) {
-        uint2 rv[K];
+        uint4 rv[K];
         uint64_t mwv[K];
         // stage A: K records and mask words in flight together
 #pragma unroll
         for (int j = 0; j < K; j++) {
             int w = w0 + j, r = w * 64 + lane;
-            rv[j] = (w < nWords && r < nRef) ? rf[r] : make_uint2(0u, 0u);
+            rv[j] = (w < nWords && r < nRef) ? rf[r] : make_uint4(0u, 0u, 0u, 0u);
             mwv[j] = w < nWords ? ld_sc1(maskIn + w) : 0;
         }
         int bit[K], cost[K], lim[K];
         bool undec[K], act[K];
-        D4GLitWalk lw[K];
-        // stage B: costs and the first two words of each record's bytes
+        D4GRecWalk lw[K];
+        // stage B: costs; the first eight bytes of each record came with it
 #pragma unroll
         for (int j = 0; j < K; j++) {
             bit[j] = (int)((mwv[j] >> lane) & 1);
@@ -362,11 +404,11 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
             undec[j] = act[j];
             cost[j] = 0;
             lim[j] = 0;
-            lw[j].widx = 0; lw[j].cur = lw[j].nxt = 0; lw[j].sh = 0; lw[j].rem = 0; lw[j].total = 0;
+            lw[j].b0 = lw[j].b1 = 0; lw[j].widx = 0; lw[j].cur = lw[j].nxt = 0; lw[j].sh = 0; lw[j].step = 0; lw[j].rem = 0; lw[j].total = 0;
             if (act[j]) {
                 cost[j] = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);  // getLitLenSize — :112-131
                 lim[j] = cost[j] + (prune ? 1 : 0);
-                lw_start(lw[j], Uw, rv[j].y, len);
+                rw_start(lw[j], Uw, rv[j], len);
             }
         }
         // stage C: the K bounded literal sums advance in lock step, four bytes each per turn
@@ -378,7 +420,7 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 if (undec[j]) {
-                    lw_step(lw[j], Uw, lc);
+                    rw_step(lw[j], Uw, lc);
                     if (lw[j].total >= lim[j] || lw[j].rem <= 0) undec[j] = false;
                 }
             }
@@ -401,9 +443,20 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
             }
         }
     }
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    pp2 = d4g_clock_drained();
+#endif
     long long saved = wg_sum_i64((long long)savedLane, L->red);
     if (threadIdx.x == 0) { S->sizeBits -= saved; S->litlenBits -= saved; }
     __syncthreads();
+#if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
+    if (threadIdx.x == 0) {
+        atomicAdd(&d4g_dbg_pass[0], (unsigned long long)(pp1 - pp0));
+        atomicAdd(&d4g_dbg_pass[1], (unsigned long long)(pp2 - pp1));
+        atomicAdd(&d4g_dbg_pass[2], 1ULL);
+        atomicAdd(&d4g_dbg_pass[3], (unsigned long long)nRef);
+    }
+#endif
     if (mine) {   // publish: histogram deltas, the outgoing mask, then the flag
         for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) st_sc1((uint32_t*)&mine->delta[i], (uint32_t)((int)S->hist[i] - histBefore[i]));
         if (threadIdx.x == 0) {
@@ -426,17 +479,23 @@ __global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blo
     if (b.binStat < 0) return;
     for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) T[i] = 0;
     __syncthreads();
-    const uint2* rf = c.refs + b.refStart;
+    const uint4* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     uint64_t* bm = c.binMask + b.binMask;
     const int lane = threadIdx.x & 63;
     const int nRef = (int)b.refCount, nWords = (int)b.maskWords;
     for (int r0 = 0; r0 < nWords * 64; r0 += blockDim.x) {
         int r = r0 + threadIdx.x;
-        uint2 rv = r < nRef ? rf[r] : make_uint2(0u, 0u);
+        uint4 rv = r < nRef ? rf[r] : make_uint4(0u, 0u, 0u, 0u);
         int len = ref_len(rv.x);
         int bin = ref_lsym(rv.x) - 257;
         if (len > 0) {
+            // the record's copy of its first eight decoded bytes (U is padded)
+            const uint32_t* uw = (const uint32_t*)Ub + (rv.y >> 2);
+            const int sh = (int)(rv.y & 3u) * 8;
+            uint32_t w0 = uw[0], w1 = uw[1], w2 = uw[2];
+            c.refs[b.refStart + r].z = d4g_alignbit(w1, w0, sh);
+            c.refs[b.refStart + r].w = d4g_alignbit(w2, w1, sh);
             uint32_t* row = T + bin * D4G_BINSTRIDE;
             atomicAdd(&row[D4G_BIN_DIST + ref_dsym(rv.x)], 1u);
             atomicAdd(&row[D4G_BIN_COUNT], 1u);
@@ -478,7 +537,7 @@ D4G_DEV int d4g_ref_lit_total(const uint32_t* Uw, const uint16_t* lc, uint32_t o
 // Calls fn(record index, record) for the records whose bit is set in sel(w) (w = mask word index), 64 at a time:
 // set bits are queued in LDS until a full wave's worth is there, so the lanes stay busy on sparse selections.
 template <typename Sel, typename Fn>
-D4G_DEV void wave_for_selected(int wave, int nw, int nWords, int nRef, const uint2* rf, uint32_t* queue /* [128] per wave */, Sel sel,
+D4G_DEV void wave_for_selected(int wave, int nw, int nWords, int nRef, const uint4* rf, uint32_t* queue /* [128] per wave */, Sel sel,
                                Fn fn) {
     const int lane = threadIdx.x & 63;
     int pending = 0;
@@ -536,7 +595,7 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
     if (threadIdx.x == 0) *npop = 0;
     wg_fill_lit_cost(L);
     const uint16_t* lc = L->litCost;
-    const uint2* rf = c.refs + b.refStart;
+    const uint4* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     const uint32_t* Uw = (const uint32_t*)Ub;
     const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
@@ -571,7 +630,7 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
             __syncthreads();
             // correction: the expanded records do not count
             if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ld_sc1(maskIn + w); },
-                              [&](int, uint2 rv) {
+                              [&](int, uint4 rv) {
                                   uint32_t a = rv.x;
                                   int bin = ref_lsym(a) - 257;
                                   int cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
@@ -582,7 +641,7 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
                               });
         } else {
             if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ~ld_sc1(maskIn + w); },
-                              [&](int, uint2 rv) {
+                              [&](int, uint4 rv) {
                                   uint32_t a = rv.x;
                                   int bin = ref_lsym(a) - 257;
                                   int cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
@@ -643,7 +702,7 @@ __device__ __forceinline__ void wg_least(D4GLds* L, const D4GCtx& c, const D4GBl
     }
     // what the already expanded records of the bin contributed to the static row (they were moved earlier)
     if (wave < nwq) wave_for_selected(wave, nwq, nWords, nRef, rf, queues + 128 * wave, [&](int w) { return ld_sc1(maskIn + w) & bm[w]; },
-                      [&](int, uint2 rv) {
+                      [&](int, uint4 rv) {
                           uint32_t a = rv.x;
                           atomicAdd(&delta[D4G_BIN_DIST + ref_dsym(a)], 1);
                           atomicAdd(&delta[D4G_BIN_COUNT], 1);
@@ -743,6 +802,9 @@ __device__ __forceinline__ void wg_rewrite_header(D4GLds* L, int flags) {
     if (threadIdx.x < 20) L->clFreq[threadIdx.x] = 0;
     __syncthreads();
     if (threadIdx.x < 64) {
+#ifndef D4G_HOSTSIM
+        __builtin_amdgcn_s_setprio(3);   // the workgroup's other waves wait for this one
+#endif
         const int lane = threadIdx.x;
         const int nLit = S->nLit, n = nLit + S->nDist;
         auto len = [&](int i) { return i < nLit ? (int)S->litLen[i] : (int)S->distLen[i - nLit]; };
@@ -805,6 +867,9 @@ __device__ __forceinline__ void wg_rewrite_header(D4GLds* L, int flags) {
         }
         d4g_wave_sync();
         w0_remove_trailing_header_codes(S);
+#ifndef D4G_HOSTSIM
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
         if (lane == 0) {
             atomicAdd(&d4g_dbg_hdr[0], (unsigned long long)(r1 - r0));

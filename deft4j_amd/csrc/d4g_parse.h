@@ -395,7 +395,7 @@ struct D4GParseOut {
     uint2* tok;
     uint8_t* U;
     D4GState* states;
-    uint2* refs;        // back-reference records (d4g_types.h), in token order
+    uint4* refs;        // back-reference records (d4g_types.h), in token order; .z/.w are filled in after the bytes are resolved
     uint32_t* tokRef;   // per token: index of its back-reference record (written for back-references only)
 };
 
@@ -564,7 +564,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     unsigned nTok = 0, nU = 0, nRef = 0, litlenBits = 0;
     int needHist = 0;
     uint2* tokOut = EMIT ? out.tok + em->tokStart : nullptr;
-    uint2* refOut = EMIT ? out.refs + em->refStart : nullptr;
+    uint4* refOut = EMIT ? out.refs + em->refStart : nullptr;
     uint32_t* tokRefOut = EMIT ? out.tokRef + em->tokStart : nullptr;
     const uint32_t refBase32 = EMIT ? (uint32_t)em->refStart : 0u;
     const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
@@ -610,7 +610,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                     atomicAdd(&S->hist[sym], 1u);
                     atomicAdd(&S->hist[D4G_NLIT + ds], 1u);
                     tokOut[tokAt + n] = make_uint2((uint32_t)len | ((uint32_t)edge << 15) | ((uint32_t)dist << 16), uStart32 + uAt + u);
-                    refOut[refAt + r] = make_uint2(d4g_ref_pack(len, sym, ds, eb + deb), uStart32 + uAt + u);
+                    refOut[refAt + r] = make_uint4(d4g_ref_pack(len, sym, ds, eb + deb), uStart32 + uAt + u, 0u, 0u);
                     tokRefOut[tokAt + n] = refBase32 + refAt + r;
                 }
                 n++; r++;

@@ -10,10 +10,12 @@
 //             .x  literal byte | 256 (EOB) | match length, dist << 16 (0 for literals/EOB),
 //                 bit 15 = the 284-as-258 edge case (DeflateBlockHuffman.java:843)
 //             .y  offset of the token's decoded bytes in U (the stream's decoded data)
-//   refs[r]   2 x u32, one record per back-reference token, in token order (the search's token passes
-//             read only these — literals never change):
+//   refs[r]   4 x u32 (one 16-byte load), one record per back-reference token, in token order (the search's
+//             token passes read only these — literals never change):
 //             .x  length | (length symbol - 257) << 9 | distance symbol << 14 | extra bits << 19
 //             .y  offset of its decoded bytes in U
+//             .z .w  its first eight decoded bytes (most literal-cost comparisons are decided within them, so a
+//                    pass iteration needs no dependent load from U)
 //   tokRef[t] u32  index into refs of back-reference token t (the writer's way from a token to its mask bit)
 //   binStat / binMask  per block and length symbol: byte / distance-symbol / record statistics of its records and
 //             the bit mask of its records (static; see D4G_NBINS below)

@@ -285,6 +285,7 @@ int d4g_debug_opstats(long long* out64) {
     (void)hipMemcpyFromSymbol(out64 + 56, HIP_SYMBOL(d4g_dbg_counters), 7 * 8);
     (void)hipMemcpyFromSymbol(out64 + 28, HIP_SYMBOL(d4g_dbg_hdr), 4 * 8);
     (void)hipMemcpyFromSymbol(out64 + 16, HIP_SYMBOL(d4g_dbg_tree), 3 * 8);
+    (void)hipMemcpyFromSymbol(out64 + 34, HIP_SYMBOL(d4g_dbg_pass), 4 * 8);
     return 0;
 }
 #endif

@@ -39,6 +39,8 @@ if buf[56]:
     print("lit tree (mean cycles): leaves %.0f  merges %.0f  depths %.0f" % (buf[16] / buf[56], buf[17] / buf[56], buf[18] / buf[56]))
 print("wave trees: lit %d (limiter %d, mean leaves %.1f)  dist %d (limiter %d)  code-length %d (limiter %d)"
       % (buf[56], buf[57], buf[58] / max(1, buf[56]), buf[59], buf[60], buf[61], buf[62]))
+if buf[36]:
+    print("computed replace passes (mean cycles): memo lookup %.0f  record loop %.0f  (n=%d, mean records %.0f)" % (buf[34] / buf[36], buf[35] / buf[36], buf[36], buf[37] / buf[36]))
 print("token passes: %d computed, %d served from the memo (mean wait %.0f cycles)" % (buf[19], buf[33], buf[32] / max(1, buf[33])))
 for arg in (0, 1):
     for k, nm in names.items():
