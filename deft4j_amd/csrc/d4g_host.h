@@ -443,6 +443,8 @@ inline Engine& engine() {
 struct HBlock {
     int type = 0;        // current type (a Huffman block may have become STORED)
     int gpu = -1;        // device block index (Huffman blocks and merge arenas)
+    int homeGpu = -1;    // device block of the first parsed block this one covers: where a merged block is committed
+    int ordinal = 0;     // that first block's position among the stream's parsed blocks
     i64 tokStart = 0, tokCount = 0, uStart = 0, uLen = 0;
     i64 refStart = 0, refCount = 0;   // back-reference records of the block's tokens
     i64 size = 0;        // Huffman: sizeBits of the current state
@@ -463,6 +465,7 @@ struct HStream {
     i64 tokBase = 0, uBase = 0, nTok = 0, nU = 0, refBase = 0, nRef = 0;
     i64 outWordBase = 0, outBits = 0;
     int arena[2] = {-1, -1};
+    i64 commitMaskBase = 0;   // mask words where finished merged blocks keep their final mask (see commit_block)
     // mergeBlocks state machine
     size_t mIdx = 0;
     i64 mPos = 0, mSaved = 0;
@@ -766,9 +769,11 @@ struct Batch {
                     hb.gpu = add_block((int)si, hb.tokStart, hb.tokCount, hb.refStart, hb.refCount, hb.uStart, hb.uLen, (hb.refCount + 63) / 64,
                                        pb.type);
                     em.stateIdx = hBlocks[hb.gpu].stateIdx;
+                    hb.homeGpu = hb.gpu;
                     realBlocks.push_back(hb.gpu);
                     nHuff++;
                 }
+                hb.ordinal = (int)s.blocks.size();
                 emits.push_back(em);
                 ranges.push_back({(int32_t)si, pb.type == D4G_STORED ? 1 : 0, hb.tokStart, hb.tokCount, upos, pb.uLen});
                 s.blocks.push_back(hb);
@@ -783,6 +788,9 @@ struct Batch {
             stats.bytes_decoded += P.nU;
             if (merge && needSlots && nHuff >= 2) {
                 for (int a = 0; a < 2; a++) s.arena[a] = add_block((int)si, s.tokBase, 0, s.refBase, 0, 0, 0, (s.nRef + 63) / 64 + 1, D4G_FIXED);
+                // a finished merged block moves out of its arena (the two arenas are re-used by the next chain of merges)
+                s.commitMaskBase = maskWordsTotal;
+                maskWordsTotal += (s.nRef + 63) / 64 + (i64)P.blocks.size() + 2;
             }
         }
         size_t nb = hBlocks.size();
@@ -1170,7 +1178,7 @@ struct Batch {
                 s.blocks.erase(s.blocks.begin() + s.mIdx);
                 break;
             }
-            if (finishPass) { s.mIdx++; s.mFirst = false; }
+            if (finishPass) { commit_block(si, s.mIdx); s.mIdx++; s.mFirst = false; }
         }
         s.mDone = true;
         return false;
@@ -1187,6 +1195,8 @@ struct Batch {
         m.tokCount = cur.tokCount + next.tokCount;
         m.refStart = cur.refStart;
         m.refCount = cur.refCount + next.refCount;
+        m.homeGpu = cur.homeGpu;
+        m.ordinal = cur.ordinal;
         m.uStart = cur.uStart;
         m.uLen = uLen;
         i64 ss = 0;
@@ -1201,12 +1211,43 @@ struct Batch {
             finishPass = false;
         }
         s.mPos += s.blocks[s.mIdx].size_at(s.mPos);
-        if (finishPass) { s.mIdx++; s.mFirst = false; }
+        if (finishPass) { commit_block(si, s.mIdx); s.mIdx++; s.mFirst = false; }
         s.mWaiting = false;
+    }
+    // A merged block that the walk has finished with lives in one of the stream's two arenas, which the next chain of
+    // merges will overwrite: move its descriptor, state and mask to the device block of the first parsed block it covers
+    // (that block is dead now) and to the stream's commit mask area (disjoint by construction: word offset =
+    // first record / 64 + position of that first block).
+    std::vector<D4GMergeJob> pendingCommits;
+    void commit_block(int si, size_t idx) {
+        HStream& s = streams[si];
+        HBlock& hb = s.blocks[idx];
+        if (hb.gpu < 0 || (hb.gpu != s.arena[0] && hb.gpu != s.arena[1])) return;
+        const int home = hb.homeGpu;
+        D4GBlock d = hBlocks[hb.gpu];
+        d.stateIdx = hBlocks[home].stateIdx;
+        d.maskBase = s.commitMaskBase + ((hb.refStart - s.refBase) >> 6) + hb.ordinal;
+        d.maskWords = (hb.refCount + 63) / 64;
+        d.binStat = -1;
+        d.passMemo = -1;
+        hBlocks[home] = d;
+        gpuType[home] = gpuType[hb.gpu];
+        rt_h2d(dBlocks + home, &hBlocks[home], sizeof(D4GBlock));
+        pendingCommits.push_back({hb.gpu, 0, home, 0});
+        hb.gpu = home;
+    }
+    void flush_commits(D4GMergeJob* dJobs) {
+        if (pendingCommits.empty()) return;
+        rt_h2d(dJobs, pendingCommits.data(), pendingCommits.size() * sizeof(D4GMergeJob));
+        D4GCtx c = make_ctx(engine().progFixed, 0);
+        RT_LAUNCH(k_commit_merged, pendingCommits.size(), 256, c, dJobs);
+        stats.kernel_launches++;
+        rt_sync();   // (the job list is re-used right away)
+        pendingCommits.clear();
     }
     void phase_merge() {
         Engine& E = engine();
-        D4GMergeJob* dJobs = (D4GMergeJob*)rt_malloc(streams.size() * sizeof(D4GMergeJob) + 16);
+        D4GMergeJob* dJobs = (D4GMergeJob*)rt_malloc(2 * streams.size() * sizeof(D4GMergeJob) + 64);
         while (true) {
             std::vector<MergeReq> reqs;
             std::vector<D4GMergeJob> jobs;
@@ -1225,6 +1266,7 @@ struct Batch {
                     rt_h2d(dBlocks + rq.arena, &hBlocks[rq.arena], sizeof(D4GBlock));
                 }
             }
+            flush_commits(dJobs);   // before any arena is overwritten
             if (reqs.empty()) break;
             rt_h2d(dJobs, jobs.data(), jobs.size() * sizeof(D4GMergeJob));
             D4GCtx c = make_ctx(E.progFixed, 0);

@@ -275,6 +275,21 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
     wg_store_state(state_ptr(c, job.blkM, 0), S);
 }
 
+// A finished merged block leaves its arena: state slot 0 and the current mask of `blkA` are copied to slot 0 / mask 0
+// of `blkM` (whose descriptor the host has already rewritten to the merged token range).
+__global__ void __launch_bounds__(256) k_commit_merged(D4GCtx c, const D4GMergeJob* jobs) {
+    const D4GMergeJob job = jobs[blockIdx.x];
+    const D4GBlock bA = c.blocks[job.blkA], bM = c.blocks[job.blkM];
+    const D4GState* sA = state_ptr(c, job.blkA, 0);
+    D4GState* sM = state_ptr(c, job.blkM, 0);
+    const uint64_t* mA = mask_ptr(c, bA, sA->maskSlot);
+    uint64_t* mM = mask_ptr(c, bM, 0);
+    for (long long w = threadIdx.x; w < bM.maskWords; w += blockDim.x) mM[w] = mA[w];
+    for (int i = threadIdx.x; i < (int)(sizeof(D4GState) / 4); i += blockDim.x) ((uint32_t*)sM)[i] = ((const uint32_t*)sA)[i];
+    __syncthreads();
+    if (threadIdx.x == 0) sM->maskSlot = 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // Trailer checksums over the decoded bytes: CRC-32 + ISIZE for gzip members
 // (K/GZFile.java:129-145, java.util.zip.CRC32) and Adler-32 for zlib streams (K/ZLibFile.java:41-51).

@@ -155,3 +155,16 @@ def test_memos_change_nothing(D, monkeypatch):
         assert outs[0] == outs[1]
         for i, a in enumerate(ins):
             assert zlib.decompress(outs[0][i][1], -15) == zlib.decompress(a, -15)
+
+
+def test_fuzz_regressions(D):
+    """Inputs the randomized run (scripts/gpu_fuzz.py) found: kept as fixtures, checked against the oracle."""
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in sorted(n for n in os.listdir(G) if n.startswith("fuzz_")):
+        a = open(os.path.join(G, name), "rb").read()
+        for merge in (False, True):
+            rc, want, saved, _, _ = O.optimise(a, merge)
+            b = D.Batch([a]).run(merge)
+            r = b.result(0)
+            assert r["status"] == rc and r["saved_bits"] == saved and b.output(0) == (want if rc == 0 else a), (name, merge)
+            b.close()

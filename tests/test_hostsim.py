@@ -119,3 +119,20 @@ def test_least_expensive_pass_both_directions(sim, monkeypatch):
         b = D.Batch([a], lib=L).run(p["merge_blocks"])
         assert b.result(0)["saved_bits"] == p["saved_bits"] and b.output(0) == rd(stem + ".out.deflate")
         b.close()
+
+
+def test_two_merge_chains_in_one_stream(sim):
+    """mergeBlocks can finish one merged block and start merging further down the stream; the finished block must
+    survive the re-use of the merge arenas (found by scripts/gpu_fuzz.py: eight blocks that merge four and four)."""
+    import random
+    D, L = sim
+    rng = random.Random(3)
+    t = synth.reptext(6000, 4)
+    parts = [t[i:i + 1500] for i in range(0, 6000, 1500)] + [bytes(rng.randrange(200, 256) for _ in range(1500)) for _ in range(4)]
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+    a = b"".join(c.compress(p) + c.flush(zlib.Z_BLOCK) for p in parts) + c.flush()
+    rc, want, saved, _, _ = O.optimise(a, True)
+    assert rc == 0 and sum(1 for bi in O.block_info(want) if bi[1] > 3000) == 2   # two merged blocks
+    b = D.Batch([a], lib=L).run(True)
+    assert b.result(0)["saved_bits"] == saved and b.output(0) == want
+    b.close()
