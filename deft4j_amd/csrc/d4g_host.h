@@ -519,6 +519,7 @@ struct Batch {
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
         c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
+        c.tileGroups = nActive > 0 ? (nActive + 7) / 8 : 1;
         return c;
     }
 
@@ -969,6 +970,12 @@ struct Batch {
                 c.active = dActive + lo;
                 rt_stream_wait(uploaded);
                 i64 groups = (hi - lo + 7) / 8;
+                {   // launch tiles (d4g_map_wg): the whole group by default
+                    static int tg = -1;
+                    if (tg < 0) { const char* t = getenv("D4G_TILE_GROUPS"); tg = t ? atoi(t) : 0; }
+                    c.tileGroups = tg > 0 && tg < groups ? tg : (int)groups;
+                    groups = (groups + c.tileGroups - 1) / c.tileGroups * c.tileGroups;
+                }
                 // Level l's header searches read bases produced at level l-1, so they run on the lane's second
                 // stream beside level l's state ops (the searches are LDS-bound at low occupancy).
                 RtEvent* lvlPrev = nullptr;

@@ -122,6 +122,7 @@ struct D4GCtx {
     int32_t nOps;
     int32_t slotsPerBlock;
     int32_t masksPerBlock;
+    int32_t tileGroups;       // blocks per launch tile / 8 (d4g_map_wg)
 };
 
 // LDS working set of one state-op workgroup
@@ -1375,14 +1376,18 @@ __device__ __forceinline__ void d4g_exec_state_op(D4GLds* L, const D4GCtx& c, in
 // XCD-aware (block, op) mapping: workgroups g and g+8 share an XCD (and its L2), so all ops
 // of one deflate block are given workgroup ids that are equal mod 8 — they re-read the same
 // tokens and decoded bytes.  Speed only; nothing depends on placement.
-D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int& blkSlot, int& opRel) {
-    // op-major: the level's ops are sorted longest first, and every block's long ops should start before anyone's
-    // short ones (the short ones then fill the tail of the launch)
+// Blocks are taken in tiles of 8 x tileGroups (D4G_TILE_GROUPS, default: the whole launch is one tile); inside a tile
+// the order is op-major: the level's ops are sorted longest first, so every block's long ops start before anyone's
+// short ones and the short ones fill the tail.  Smaller tiles keep a block's ops closer in time (less L2 re-fetch,
+// measured 152 -> 53 MB per launch with 64-block tiles) but cost ~7 % in time: HBM is nowhere near the limit here.
+D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int tileGroups, int& blkSlot, int& opRel) {
     int g = blockIdx.x;
     int x = g & 7, j = g >> 3;
-    int nGroups = (nActive + 7) >> 3;
-    opRel = j / nGroups;
-    int local = j - opRel * nGroups;
+    int perTile = tileGroups * nOpsLevel;
+    int tile = j / perTile;
+    int rem = j - tile * perTile;
+    opRel = rem / tileGroups;
+    int local = tile * tileGroups + (rem - opRel * tileGroups);
     blkSlot = local * 8 + x;
     return blkSlot < nActive && opRel < nOpsLevel;
 }
@@ -1390,7 +1395,7 @@ D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int& blkSlot, int& opRel) {
 __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(7) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
     __shared__ D4GLds L;
     int bs, orel;
-    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
@@ -1399,7 +1404,7 @@ __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(7) k_exec_state_ops(D4
 __global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const int32_t* opList, int nOpsLevel) {
     __shared__ D4GLds L;
     int bs, orel;
-    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
@@ -1705,7 +1710,7 @@ __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t*
     __shared__ D4GHdrLds H;
     __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
     int bs, orel;
-    if (!d4g_map_wg(c.nActive, nOpsLevel, bs, orel)) return;
+    if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
     d4g_exec_hdr_search(H, comb, c, c.active[bs], opList[orel]);
 }
 
