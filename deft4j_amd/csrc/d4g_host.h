@@ -850,15 +850,17 @@ struct Batch {
             i64 maxU = 0;
             for (size_t i = 0; i < n; i++) maxU = std::max(maxU, ps[i].nU);
             int G = (int)std::min<i64>(2048, std::max<i64>(1, (maxU + 4095) / 4096));
-            int32_t* dChanged = (int32_t*)rt_malloc(16);
+            unsigned long long* dChanged = (unsigned long long*)rt_malloc(16);
+            i64 totalU = 0;
+            for (size_t i = 0; i < n; i++) totalU += ps[i].nU;
             for (int round = 0; round < 40; round++) {
-                rt_memset(dChanged, 0, 4);
+                rt_memset(dChanged, 0, 8);
                 RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged, G);
                 stats.kernel_launches++;
-                int32_t ch = 0;
-                rt_d2h(&ch, dChanged, 4);
+                unsigned long long ch = 0;
+                rt_d2h(&ch, dChanged, 8);
                 stats.jump_rounds++;
-                if (!ch) break;
+                if ((i64)ch * 4 < totalU) break;   // under a quarter of the bytes still moving: the resolve pass walks the rest
             }
             RT_LAUNCH(k_resolve_streams, n * (size_t)G, 256, dStreams, dSrc, dU, G);
             stats.kernel_launches++;

@@ -797,12 +797,12 @@ __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, 
 }
 
 // One stream per blockIdx.y.  In place: reading a concurrently updated entry still yields an ancestor.
-__global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* streams, uint32_t* src, int32_t* changed, int G) {
+__global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* streams, uint32_t* src, unsigned long long* changed, int G) {
     const D4GStreamDesc sd = streams[blockIdx.x / G];
     uint32_t* s = src + sd.uBase;   // uBase is a multiple of 16: four entries per 16-byte load
     const long long n4 = sd.uLen >> 2;
     long long stride = (long long)G * blockDim.x;
-    int any = 0;
+    int any = 0;   // entries this thread moved
     // four consecutive entries per thread and step: one coalesced 16-byte load, four gathers in flight
     for (long long q4 = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q4 < n4; q4 += stride) {
         const uint32_t q = (uint32_t)(q4 << 2);
@@ -811,17 +811,18 @@ __global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* strea
         bool c0 = b0 != a.x, c1 = b1 != a.y, c2 = b2 != a.z, c3 = b3 != a.w;
         if (c0 | c1 | c2 | c3) {
             *(uint4*)(s + q) = make_uint4(b0, b1, b2, b3);
-            any = 1;
+            any += (int)c0 + (int)c1 + (int)c2 + (int)c3;
         }
     }
     if (blockIdx.x % G == 0 && threadIdx.x < (sd.uLen & 3)) {   // the last one to three entries
         long long q = (n4 << 2) + threadIdx.x;
         uint32_t a = s[q];
         uint32_t b = s[a];
-        if (b != a) { s[q] = b; any = 1; }
+        if (b != a) { s[q] = b; any++; }
     }
-    unsigned long long m = __ballot(any);
-    if (m && (threadIdx.x & 63) == 0) atomicOr((unsigned*)changed, 1u);
+    // how many entries moved this round (the host stops doubling once few do; k_resolve_streams walks the rest)
+    int tot = wave_sum_i32(any);
+    if (tot && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)changed, (unsigned long long)tot);
 }
 __global__ void __launch_bounds__(256) k_resolve_streams(const D4GStreamDesc* streams, const uint32_t* src, uint8_t* U, int G) {
     const D4GStreamDesc sd = streams[blockIdx.x / G];
@@ -830,6 +831,10 @@ __global__ void __launch_bounds__(256) k_resolve_streams(const D4GStreamDesc* st
     long long stride = (long long)G * blockDim.x;
     for (long long q = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q < sd.uLen; q += stride) {
         uint32_t a = s[q];
-        if (a != (uint32_t)q) u[q] = u[a];
+        if (a != (uint32_t)q) {
+            // (pointer doubling stops early: follow what is left of the chain — every hop lands on an ancestor)
+            for (uint32_t b = s[a]; b != a; b = s[a]) a = b;
+            u[q] = u[a];
+        }
     }
 }
