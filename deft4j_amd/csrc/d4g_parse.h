@@ -235,10 +235,12 @@ __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* strea
     long long nbits = sd.len * 8;
     int lane = threadIdx.x & 63;
     for (int b = threadIdx.x; b < D4G_SCAN_TILE; b += blockDim.x) {
-        uint64_t lo = 0;   // 96 bits starting at byte b
-        uint32_t hi = 0;
-        for (int k = 0; k < 8; k++) lo |= (uint64_t)buf[b + k] << (8 * k);
-        for (int k = 0; k < 4; k++) hi |= (uint32_t)buf[b + 8 + k] << (8 * k);
+        // 96 bits starting at byte b: four aligned words of the tile, shifted into place
+        const uint32_t* bw = (const uint32_t*)buf + (b >> 2);
+        const int bsh = (b & 3) * 8;
+        const uint32_t w0 = bw[0], w1 = bw[1], w2 = bw[2], w3 = bw[3];
+        uint64_t lo = (uint64_t)d4g_alignbit(w1, w0, bsh) | ((uint64_t)d4g_alignbit(w2, w1, bsh) << 32);
+        uint32_t hi = d4g_alignbit(w3, w2, bsh);
         long long bit0 = (tile.byteStart + b) * 8;
         for (int s = 0; s < 8; s++) {
             uint64_t v = s ? ((lo >> s) | ((uint64_t)hi << (64 - s))) : lo;   // window bits 0..63
