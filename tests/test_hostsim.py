@@ -136,3 +136,18 @@ def test_two_merge_chains_in_one_stream(sim):
     b = D.Batch([a], lib=L).run(True)
     assert b.result(0)["saved_bits"] == saved and b.output(0) == want
     b.close()
+
+
+def test_scan_prefilter_probe_find_every_dynamic_block(sim):
+    """The header scan + lane-per-candidate pre-filter must hand every dynamic block to the probe: a block they miss
+    is still parsed (the chain walk probes unseen positions one by one) but serially — so count those probes."""
+    D, L = sim
+    raw = synth.reptext(300000, 9)
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 8)
+    a = b"".join(c.compress(raw[i:i + 20000]) + c.flush(zlib.Z_BLOCK) for i in range(0, len(raw), 20000)) + c.flush()
+    nblocks = len(O.block_info(a))
+    b = D.Batch([a], lib=L).parse()
+    st = b.stats()
+    assert b.decoded(0) == raw
+    assert st["n_blocks"] == nblocks and st["scan_confirmed"] >= nblocks - 2 and st["exact_probes"] <= 2, st
+    b.close()
