@@ -42,7 +42,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("D4G_LIB") or LIB_PATH   # D4G_LIB: development builds of the same library
     if not os.path.exists(p):
         raise RuntimeError("libdeft4g.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                            "there is no CPU fallback" % p)

@@ -184,7 +184,9 @@ D4G_DEV void for_bytes(const uint8_t* p, int len, Fn fn) {
         have = 4;
     }
 }
+#ifndef D4G_LONG_TOKEN
 #define D4G_LONG_TOKEN 32  // back-references longer than this are summed by the whole wave
+#endif
 #define D4G_NO_CODE 0x4000 // literal cost of a byte whose symbol has no code: above any real sum (258 * 15)
 
 // litCost[v] for the state's current literal/length code (ends with a barrier)
@@ -348,7 +350,9 @@ __device__ __forceinline__ void wg_passmemo_apply(D4GLds* L, const D4GBlock& b, 
 // the same as comparing the whole sum — lanes stop as soon as the bound is reached.
 // The histogram follows the token list (back-reference symbols out, literal bytes in).
 // ---------------------------------------------------------------------------------------
-#define D4G_TOK_ILP 2  // records per lane per step: independent chains hide LDS / L2 latency
+#ifndef D4G_TOK_ILP
+#define D4G_TOK_ILP 1  // records per lane per step (2 and 4 measured slower now that a record carries its first bytes)
+#endif
 __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, const D4GBlock& b, const uint64_t* maskIn, uint64_t* maskOut,
                                     bool prune) {
     D4GState* S = &L->st;
