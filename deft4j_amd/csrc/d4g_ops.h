@@ -81,7 +81,9 @@ static_assert(offsetof(D4GState, litLen) == 64 && offsetof(D4GState, hist) == 64
 // histogram changes and the bits saved — depends only on the two codes, the incoming mask and the strict/lenient
 // comparison; many candidate states of a block share all of those.  Entry = header, the 320 histogram deltas, the
 // outgoing mask (memo-owned copy, so entries stay valid across rounds).  Cleared when a merge arena is re-used.
-#define D4G_PASSMEMO_SLOTS 128
+#ifndef D4G_PASSMEMO_SLOTS
+#define D4G_PASSMEMO_SLOTS 256   // a block sees ~250 distinct (codes, mask) pairs per run; 128 slots overflowed
+#endif
 struct D4GPassMemo {
     unsigned long long tag, check;
     int32_t state, pad;
@@ -1396,7 +1398,10 @@ D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int tileGroups, int& blkSlot
     return blkSlot < nActive && opRel < nOpsLevel;
 }
 
-__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(7) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+#ifndef D4G_STATE_WAVES
+#define D4G_STATE_WAVES 8
+#endif
+__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_STATE_WAVES) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
     __shared__ D4GLds L;
     int bs, orel;
     if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
