@@ -34,7 +34,10 @@ D4G_DEV void d4g_flag_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOM
 D4G_DEV void d4g_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 D4G_DEV void d4g_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 D4G_DEV void d4g_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(8); }
+#ifndef D4G_SPIN_SLEEP
+#define D4G_SPIN_SLEEP 8
+#endif
+D4G_DEV void d4g_sleep() { __builtin_amdgcn_s_sleep(D4G_SPIN_SLEEP); }
 #endif
 
 
@@ -53,7 +56,9 @@ D4G_DEV long long d4g_clock_drained() {
 // Header-search memo.  The 56 header candidates of a state depend only on its code lengths, and most of a block's
 // ~200 header searches per run see value-identical lengths (a Huffman code hardly moves when a few tokens change):
 // the first search of a length set owns the entry and publishes (header bits, winning candidate); the others reuse it.
+#ifndef D4G_HSMEMO_SLOTS
 #define D4G_HSMEMO_SLOTS 64
+#endif
 struct D4GHsMemo {
     unsigned long long tag;     // first 64-bit hash of the length set, 0 = free
     unsigned long long check;   // second, independent hash (written by the owner before `state` turns 2)
@@ -67,7 +72,9 @@ struct D4GHsMemo {
 // the bit sizes) is a function of the symbol histogram alone, and many of a block's candidate states share a
 // histogram.  Same protocol as the header-search memo: the first rebuild of a histogram owns the entry and
 // publishes the rebuilt part of the state (bytes [64, 1056): lengths and pairs); later ones copy it.
+#ifndef D4G_RCMEMO_SLOTS
 #define D4G_RCMEMO_SLOTS 128
+#endif
 #define D4G_RCMEMO_WORDS 248
 struct D4GRecodeMemo {
     unsigned long long tag, check;
