@@ -860,7 +860,9 @@ struct Batch {
                 unsigned long long ch = 0;
                 rt_d2h(&ch, dChanged, 8);
                 stats.jump_rounds++;
-                if ((i64)ch * 4 < totalU) break;   // under a quarter of the bytes still moving: the resolve pass walks the rest
+                static int stopPct = -1;   // D4G_JUMP_STOP_PCT: stop doubling once fewer than this share of the bytes still moves
+                if (stopPct < 0) { const char* t = getenv("D4G_JUMP_STOP_PCT"); stopPct = t ? atoi(t) : 50; }
+                if ((i64)ch * 100 < totalU * stopPct) break;   // the resolve pass walks what is left of the chains
             }
             RT_LAUNCH(k_resolve_streams, n * (size_t)G, 256, dStreams, dSrc, dU, G);
             stats.kernel_launches++;
