@@ -132,7 +132,9 @@ struct D4GBitReader {
     __device__ bool near_end() const { return rel + 1024 > D4G_INCH; }
 };
 
+#ifndef D4G_CHUNK_BITS
 #define D4G_CHUNK_BITS 512   // bits per lane and pass of the wave-wide token decoder
+#endif
 static_assert(64 * D4G_CHUNK_BITS + 160 <= (D4G_INCH + 16) * 8, "a batch of 64 chunks must fit the staged input window");
 static_assert(D4G_CHUNK_BITS + 48 < 1024, "tokens per chunk must fit the 10-bit field of a chunk record");
 // 64 bits of the staged input starting at bit `posRel` (any lane, any position inside the staged chunk)
