@@ -1424,7 +1424,7 @@ __global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const in
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
-__global__ void __launch_bounds__(256) k_persist_state_ops(D4GCtx c, D4GQueue q) {
+__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_STATE_WAVES) k_persist_state_ops(D4GCtx c, D4GQueue q) {
     __shared__ D4GLds L;
     __shared__ int sTask[3], sOk;
     int cursor = 0;
