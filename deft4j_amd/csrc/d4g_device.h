@@ -115,6 +115,19 @@ D4G_DEV long long wg_sum_i64(long long v, long long* red) {
     __syncthreads();
     return red[16];
 }
+// Two workgroup-wide sums in one exchange (`red`: >= 32 long long).  All threads call; every thread adds the per-wave
+// partials itself, so there is no serial stage.
+D4G_DEV void wg_sum2_i64(long long a, long long b, long long* red, long long& sa, long long& sb) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    a = wave_sum_i64(a);
+    b = wave_sum_i64(b);
+    __syncthreads();
+    if (lane == 0) { red[wave] = a; red[16 + wave] = b; }
+    __syncthreads();
+    sa = 0; sb = 0;
+    for (int i = 0; i < nw; i++) { sa += red[i]; sb += red[16 + i]; }
+    __syncthreads();
+}
 D4G_DEV int wg_max_i32(int v, long long* red) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_max_i32(v);

@@ -296,8 +296,10 @@ __device__ __forceinline__ int wg_passmemo_lookup(D4GLds* L, const D4GCtx& c, co
         a1 += mix1(1000 + w, m);
         a2 += mix2(1000 + w, m);
     }
-    unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red) + (unsigned long long)kind * 0x51ed270b35a3ULL;
-    const unsigned long long h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red) ^ ((unsigned long long)kind * 0x9b05688c2b3e6c1fULL);
+    long long s1, s2;
+    wg_sum2_i64((long long)a1, (long long)a2, L->red, s1, s2);
+    unsigned long long h1 = (unsigned long long)s1 + (unsigned long long)kind * 0x51ed270b35a3ULL;
+    const unsigned long long h2 = (unsigned long long)s2 ^ ((unsigned long long)kind * 0x9b05688c2b3e6c1fULL);
     h2out = h2;
     if (h1 == 0) h1 = 1;
     uint64_t* pool = c.passMemo + b.passMemo;
@@ -328,12 +330,12 @@ __device__ __forceinline__ int wg_passmemo_lookup(D4GLds* L, const D4GCtx& c, co
 #ifdef D4G_PROFILE_OPS
         if (c.opStats && role != 2) atomicAdd((unsigned long long*)&c.opStats[19], 1ULL);   // passes actually computed
 #endif
-        L->red[20] = role;
-        L->red[21] = idx;
+        L->misc[62] = (int)role;
+        L->misc[63] = (int)idx;
     }
     __syncthreads();
-    const int role = (int)L->red[20];
-    entry = (D4GPassMemo*)(pool + L->red[21] * b.passMemoStride);
+    const int role = L->misc[62];
+    entry = (D4GPassMemo*)(pool + (long long)L->misc[63] * b.passMemoStride);
     __syncthreads();
     return role;
 }
@@ -1008,8 +1010,10 @@ __device__ __forceinline__ void wg_recode_huffman(D4GLds* L, D4GRecodeMemo* memo
             a1 += x;
             a2 += y;
         }
-        unsigned long long h1 = (unsigned long long)wg_sum_i64((long long)a1, L->red);
-        h2 = (unsigned long long)wg_sum_i64((long long)a2, L->red);
+        long long s1, s2;
+        wg_sum2_i64((long long)a1, (long long)a2, L->red, s1, s2);
+        unsigned long long h1 = (unsigned long long)s1;
+        h2 = (unsigned long long)s2;
         if (h1 == 0) h1 = 1;
         if (threadIdx.x == 0) {
             long long role = 0, idx = 0;   // 0 compute without the memo, 1 owner, 2 hit
@@ -1029,12 +1033,12 @@ __device__ __forceinline__ void wg_recode_huffman(D4GLds* L, D4GRecodeMemo* memo
                     break;
                 }
             }
-            L->red[20] = role;
-            L->red[21] = idx;
+            L->misc[62] = (int)role;
+            L->misc[63] = (int)idx;
         }
         __syncthreads();
-        const int role = (int)L->red[20];
-        D4GRecodeMemo* e = memoTab + (int)L->red[21];
+        const int role = L->misc[62];
+        D4GRecodeMemo* e = memoTab + L->misc[63];
         __syncthreads();
         if (role == 2) {
             for (int i = threadIdx.x; i < D4G_RCMEMO_WORDS; i += blockDim.x) ((uint32_t*)S)[16 + i] = ld_sc1(&e->body[i]);
