@@ -397,16 +397,28 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
     const uint32_t* Uw = (const uint32_t*)Ub;
     const int nWords = (int)b.maskWords, nRef = (int)b.refCount;  // a block's counts fit 31 bits
     int savedLane = 0;
+    // stage A, software-pipelined: the record and the mask word of the NEXT step are requested (branch-free, from
+    // always-valid addresses, so both loads go out back to back) before this step's are used
+    uint4 nrv[K];
+    uint64_t nmw[K];
+    auto fetch = [&](int wbase) D4G_LAMBDA_INLINE {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            int w = wbase + j, r = w * 64 + lane;
+            int wc = w < nWords ? w : 0, rc = r < nRef ? r : 0;
+            nmw[j] = nWords ? ld_sc1(maskIn + wc) : 0;
+            nrv[j] = nRef ? rf[rc] : make_uint4(0u, 0u, 0u, 0u);
+            if (r >= nRef) nrv[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (w >= nWords) nmw[j] = 0;
+        }
+    };
+    fetch(wave * K);
     for (int w0 = wave * K; w0 < nWords; w0 += nw * K) {
         uint4 rv[K];
         uint64_t mwv[K];
-        // stage A: K records and mask words in flight together
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            int w = w0 + j, r = w * 64 + lane;
-            rv[j] = (w < nWords && r < nRef) ? rf[r] : make_uint4(0u, 0u, 0u, 0u);
-            mwv[j] = w < nWords ? ld_sc1(maskIn + w) : 0;
-        }
+        for (int j = 0; j < K; j++) { rv[j] = nrv[j]; mwv[j] = nmw[j]; }
+        fetch(w0 + nw * K);
         int bit[K], cost[K], lim[K];
         bool undec[K], act[K];
         D4GRecWalk lw[K];
