@@ -413,62 +413,54 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
         }
     };
     fetch(wave * K);
-    for (int w0 = wave * K; w0 < nWords; w0 += nw * K) {
-        uint4 rv[K];
-        uint64_t mwv[K];
-#pragma unroll
-        for (int j = 0; j < K; j++) { rv[j] = nrv[j]; mwv[j] = nmw[j]; }
-        fetch(w0 + nw * K);
-        int bit[K], cost[K], lim[K];
-        bool undec[K], act[K];
-        D4GRecWalk lw[K];
-        // stage B: costs; the first eight bytes of each record came with it
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-            bit[j] = (int)((mwv[j] >> lane) & 1);
-            uint32_t a = rv[j].x;
-            int len = ref_len(a);
-            act[j] = len > 0 && !bit[j];
-            undec[j] = act[j];
-            cost[j] = 0;
-            lim[j] = 0;
-            lw[j].b0 = lw[j].b1 = 0; lw[j].widx = 0; lw[j].cur = lw[j].nxt = 0; lw[j].sh = 0; lw[j].step = 0; lw[j].rem = 0; lw[j].total = 0;
-            if (act[j]) {
-                cost[j] = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);  // getLitLenSize — :112-131
-                lim[j] = cost[j] + (prune ? 1 : 0);
-                rw_start(lw[j], Uw, rv[j], len);
-            }
+    static_assert(D4G_TOK_ILP == 1, "the straight-line first two steps below are written for one record per lane");
+    for (int w0 = wave; w0 < nWords; w0 += nw) {
+        const uint4 rec = nrv[0];
+        const uint64_t mw = nmw[0];
+        fetch(w0 + nw);
+        int bit = (int)((mw >> lane) & 1);
+        const uint32_t a = rec.x;
+        const int len = ref_len(a);
+        const bool act = len > 0 && !bit;
+        // cost of the back-reference (getLitLenSize — :112-131) and the bound its literals must stay under
+        int cost = 0, lim = 0, total = 0;
+        if (act) {
+            cost = S->litLen[ref_lsym(a)] + S->distLen[ref_dsym(a)] + ref_ebits(a);
+            lim = cost + (prune ? 1 : 0);
+            // bytes 0-3 came with the record (a back-reference has at least three bytes)
+            const uint32_t x = rec.z;
+            total = lc[x & 255u] + lc[(x >> 8) & 255u] + lc[(x >> 16) & 255u] + (len > 3 ? lc[x >> 24] : 0);
         }
-        // stage C: the K bounded literal sums advance in lock step, four bytes each per turn
-        while (true) {
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < K; j++) any |= undec[j];
-            if (!any) break;
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-                if (undec[j]) {
-                    rw_step(lw[j], Uw, lc);
-                    if (lw[j].total >= lim[j] || lw[j].rem <= 0) undec[j] = false;
+        bool undec = act && total < lim && len > 4;
+        if (__ballot(undec)) {
+            if (undec) {   // bytes 4-7, also from the record
+                const uint32_t x = rec.w;
+                const int n = len - 4;
+                total += lc[x & 255u] + (n > 1 ? lc[(x >> 8) & 255u] : 0) + (n > 2 ? lc[(x >> 16) & 255u] : 0) + (n > 3 ? lc[x >> 24] : 0);
+                undec = total < lim && len > 8;
+            }
+            if (__ballot(undec)) {
+                if (undec) {   // the rare long walk: the rest comes from U, four bytes per step
+                    D4GLitWalk lw;
+                    lw_start(lw, Uw, rec.y + 8, len - 8);
+                    lw.total = total;
+                    while (lw.rem > 0 && lw.total < lim) lw_step(lw, Uw, lc);
+                    total = lw.total;
                 }
             }
         }
-        // stage D: apply, new mask words
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-            if (act[j] && lw[j].total < lim[j]) {
-                uint32_t a = rv[j].x;
-                bit[j] = 1;
-                savedLane += cost[j] - lw[j].total;
-                atomicSub(&S->hist[ref_lsym(a)], 1u);
-                atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
-                for_bytes(Ub + rv[j].y, ref_len(a), [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
-            }
-            uint64_t nm = __ballot(bit[j]);
-            if (lane == 0 && w0 + j < nWords) {
-                st_sc1(maskOut + w0 + j, nm);
-                if (mine) st_sc1((uint64_t*)mine + D4G_PASSMEMO_HDR_WORDS + w0 + j, nm);
-            }
+        // apply: expanded when all its bytes have codes and they sum below the bound
+        if (act && total < lim) {
+            bit = 1;
+            savedLane += cost - total;
+            atomicSub(&S->hist[ref_lsym(a)], 1u);
+            atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
+            for_bytes(Ub + rec.y, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
+        }
+        uint64_t nm = __ballot(bit);
+        if (lane == 0) {
+            st_sc1(maskOut + w0, nm);
+            if (mine) st_sc1((uint64_t*)mine + D4G_PASSMEMO_HDR_WORDS + w0, nm);
         }
     }
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
