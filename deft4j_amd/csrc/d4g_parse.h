@@ -225,10 +225,14 @@ __device__ __forceinline__ int d4g_decode_sym_packed(const D4GDecTab* T, uint64_
 // ---------------------------------------------------------------------------------------
 struct D4GScanTile { int32_t stream; int32_t pad; long long byteStart; };
 #define D4G_SCAN_TILE 2048
+#define D4G_SCAN_LOCAL 1024   // candidates a workgroup collects before it touches the global list
 
 __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* streams, const D4GScanTile* tiles, D4GProbeIn* cands,
                                                       unsigned* nCands, unsigned capCands) {
     alignas(16) __shared__ uint8_t buf[D4G_SCAN_TILE + 32];
+    __shared__ uint32_t lpos[D4G_SCAN_LOCAL];   // bit offsets (inside the tile) of this workgroup's candidates
+    __shared__ unsigned lcount, gbase;
+    if (threadIdx.x == 0) lcount = 0;
     const D4GScanTile tile = tiles[blockIdx.x];
     const D4GStreamDesc sd = streams[tile.stream];
     for (int i = threadIdx.x * 16; i < D4G_SCAN_TILE + 32; i += blockDim.x * 16)
@@ -252,26 +256,43 @@ __global__ void __launch_bounds__(256) k_scan_headers(const D4GStreamDesc* strea
             int ncl = (int)((v >> 13) & 15) + 4;
             ok = ok && (p + 17 + 3 * ncl <= nbits);
             if (ok) {
-                // the code-length code must be complete: sum 2^(7-l) == 128, at least two codes
-                int kraft = 0, used = 0;
-                for (int i = 0; i < ncl; i++) {
-                    int bitIdx = 17 + 3 * i;
-                    int l = bitIdx + 3 <= 64 ? (int)((v >> bitIdx) & 7) : (int)((w >> (bitIdx - 32)) & 7);
-                    if (l) { kraft += 128 >> l; used++; }
-                }
+                // the code-length code must be complete: sum 2^(7-l) == 128, at least two codes.  Branch-free over the
+                // 3-bit fields: bit planes of the (masked) 57-bit field, one popcount per length value
+                uint64_t f = (v >> 17) | ((w >> 32) << 47);           // window bits 17..80
+                f &= (1ULL << (3 * ncl)) - 1;
+                const uint64_t M = 0x1249249249249249ULL;              // bit 0 of every 3-bit field
+                const uint64_t p0 = f & M, p1 = (f >> 1) & M, p2 = (f >> 2) & M;
+                const uint64_t n0 = ~p0, n1 = ~p1, n2 = ~p2;
+                int kraft = 64 * __popcll(p0 & n1 & n2) + 32 * __popcll(n0 & p1 & n2) + 16 * __popcll(p0 & p1 & n2) +
+                            8 * __popcll(n0 & n1 & p2) + 4 * __popcll(p0 & n1 & p2) + 2 * __popcll(n0 & p1 & p2) + __popcll(p0 & p1 & p2);
+                int used = __popcll(p0 | p1 | p2);
                 ok = kraft == 128 && used >= 2;
             }
+            // candidates are collected per workgroup (one global atomic per tile instead of one per hit: tens of
+            // thousands of atomics on a single counter were most of this kernel's time)
             unsigned long long m = __ballot(ok);
             if (m) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(nCands, (unsigned)__popcll(m));
+                if (lane == 0) base = atomicAdd(&lcount, (unsigned)__popcll(m));
                 base = __shfl(base, 0);
                 if (ok) {
                     unsigned idx = base + (unsigned)__popcll(m & ((1ULL << lane) - 1));
-                    if (idx < capCands) { D4GProbeIn c; c.stream = tile.stream; c.strict = 1; c.bitPos = p; cands[idx] = c; }
+                    if (idx < D4G_SCAN_LOCAL) lpos[idx] = (uint32_t)(p - tile.byteStart * 8);
+                    else {   // (a tile with more plausible headers than the local list holds: straight to the global list)
+                        unsigned g = atomicAdd(nCands, 1u);
+                        if (g < capCands) { D4GProbeIn c; c.stream = tile.stream; c.strict = 1; c.bitPos = p; cands[g] = c; }
+                    }
                 }
             }
         }
+    }
+    __syncthreads();
+    const unsigned nl = lcount < D4G_SCAN_LOCAL ? lcount : D4G_SCAN_LOCAL;
+    if (threadIdx.x == 0) gbase = nl ? atomicAdd(nCands, nl) : 0u;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nl; i += blockDim.x) {
+        unsigned g = gbase + i;
+        if (g < capCands) { D4GProbeIn c; c.stream = tile.stream; c.strict = 1; c.bitPos = tile.byteStart * 8 + lpos[i]; cands[g] = c; }
     }
 }
 
