@@ -845,9 +845,15 @@ __global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* strea
         uint32_t b = s[a];
         if (b != a) { s[q] = b; any++; }
     }
-    // how many entries moved this round (the host stops doubling once few do; k_resolve_streams walks the rest)
+    // how many entries moved this round (the host stops doubling once few do; k_resolve_streams walks the rest);
+    // one global atomic per workgroup
+    __shared__ unsigned wgMoved;
+    if (threadIdx.x == 0) wgMoved = 0;
+    __syncthreads();
     int tot = wave_sum_i32(any);
-    if (tot && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)changed, (unsigned long long)tot);
+    if (tot && (threadIdx.x & 63) == 0) atomicAdd(&wgMoved, (unsigned)tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && wgMoved) atomicAdd((unsigned long long*)changed, (unsigned long long)wgMoved);
 }
 __global__ void __launch_bounds__(256) k_resolve_streams(const D4GStreamDesc* streams, const uint32_t* src, uint8_t* U, int G) {
     const D4GStreamDesc sd = streams[blockIdx.x / G];
