@@ -850,15 +850,15 @@ struct Batch {
             i64 maxU = 0;
             for (size_t i = 0; i < n; i++) maxU = std::max(maxU, ps[i].nU);
             int G = (int)std::min<i64>(2048, std::max<i64>(1, (maxU + 4095) / 4096));
-            unsigned long long* dChanged = (unsigned long long*)rt_malloc(16);
+            unsigned long long* dChanged = (unsigned long long*)rt_malloc(40 * 8);   // one counter per round, zeroed once
+            rt_memset(dChanged, 0, 40 * 8);
             i64 totalU = 0;
             for (size_t i = 0; i < n; i++) totalU += ps[i].nU;
             for (int round = 0; round < 40; round++) {
-                rt_memset(dChanged, 0, 8);
-                RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged, G);
+                RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged + round, G);
                 stats.kernel_launches++;
                 unsigned long long ch = 0;
-                rt_d2h(&ch, dChanged, 8);
+                rt_d2h(&ch, dChanged + round, 8);
                 stats.jump_rounds++;
                 static int stopPct = -1;   // D4G_JUMP_STOP_PCT: stop doubling once fewer than this share of the bytes still moves
                 if (stopPct < 0) { const char* t = getenv("D4G_JUMP_STOP_PCT"); stopPct = t ? atoi(t) : 50; }
