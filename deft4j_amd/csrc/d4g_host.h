@@ -878,7 +878,7 @@ struct Batch {
             dReal = (int32_t*)rt_malloc(realBlocks.size() * 4);
             rt_h2d(dReal, realBlocks.data(), realBlocks.size() * 4);
             D4GCtx c = make_ctx(E.progDyn, 0);
-            RT_LAUNCH(k_block_bins, realBlocks.size(), 256, c, dReal);
+            RT_LAUNCH(k_block_bins, realBlocks.size() * D4G_BINS_SPLIT, 256, c, dReal);
             stats.kernel_launches++;
         }
         e1.record();

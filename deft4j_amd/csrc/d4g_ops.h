@@ -493,9 +493,11 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
 // Static per-bin statistics of a block's back-reference records (D4G_NBINS rows, d4g_types.h) and the per-bin
 // record masks.  One workgroup per block, once per parse.
 // ---------------------------------------------------------------------------------------
+#define D4G_BINS_SPLIT 4   // workgroups per block (each sums its share in LDS, then adds it to the block's zeroed table)
 __global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blockList) {
     __shared__ uint32_t T[D4G_NBINS * D4G_BINSTRIDE];
-    const D4GBlock b = c.blocks[blockList[blockIdx.x]];
+    const D4GBlock b = c.blocks[blockList[blockIdx.x / D4G_BINS_SPLIT]];
+    const int part = blockIdx.x % D4G_BINS_SPLIT;
     if (b.binStat < 0) return;
     for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) T[i] = 0;
     __syncthreads();
@@ -504,7 +506,7 @@ __global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blo
     uint64_t* bm = c.binMask + b.binMask;
     const int lane = threadIdx.x & 63;
     const int nRef = (int)b.refCount, nWords = (int)b.maskWords;
-    for (int r0 = 0; r0 < nWords * 64; r0 += blockDim.x) {
+    for (int r0 = part * (int)blockDim.x; r0 < nWords * 64; r0 += D4G_BINS_SPLIT * (int)blockDim.x) {
         int r = r0 + threadIdx.x;
         uint4 rv = r < nRef ? rf[r] : make_uint4(0u, 0u, 0u, 0u);
         int len = ref_len(rv.x);
@@ -533,8 +535,9 @@ __global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blo
         }
     }
     __syncthreads();
-    uint32_t* g = c.binStat + b.binStat;
-    for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x) g[i] = T[i];
+    uint32_t* g = c.binStat + b.binStat;   // zeroed by the host
+    for (int i = threadIdx.x; i < D4G_NBINS * D4G_BINSTRIDE; i += blockDim.x)
+        if (T[i]) atomicAdd(&g[i], T[i]);
 }
 
 // ---------------------------------------------------------------------------------------
