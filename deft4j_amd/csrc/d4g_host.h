@@ -1326,7 +1326,12 @@ struct Batch {
             D4GWriteJob* dJobs = (D4GWriteJob*)rt_malloc(jobs.size() * sizeof(D4GWriteJob));
             rt_h2d(dJobs, jobs.data(), jobs.size() * sizeof(D4GWriteJob));
             D4GCtx c = make_ctx(engine().progDyn, 0);
-            RT_LAUNCH(k_write, jobs.size(), state_block(), c, dJobs, dOut);
+#ifdef D4G_HOSTSIM
+            const int writeBlock = state_block();
+#else
+            const int writeBlock = 1024;   // one workgroup per block walks its tokens in order: wide steps, few of them
+#endif
+            RT_LAUNCH(k_write, jobs.size(), writeBlock, c, dJobs, dOut);
             stats.kernel_launches++;
             rt_sync();
             rt_free(dJobs);

@@ -60,11 +60,11 @@ struct D4GWriteLds {
     uint16_t litCode[D4G_NLIT];
     uint16_t distCode[D4G_NDIST];
     uint16_t clCode[20];
-    long long scan[8];
+    long long scan[16];
     long long base;
 };
 
-__global__ void __launch_bounds__(256) k_write(D4GCtx c, const D4GWriteJob* jobs, uint32_t* out) {
+__global__ void __launch_bounds__(1024) k_write(D4GCtx c, const D4GWriteJob* jobs, uint32_t* out) {
     __shared__ D4GWriteLds W;
     const D4GWriteJob job = jobs[blockIdx.x];
     if (job.type == D4G_STORED) {
