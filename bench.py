@@ -35,9 +35,22 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (rehearsal: several ranks on one GPU)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started by hand as `python bench.py --gpus N`: launch the N ranks (one process per GPU) the way the driver
+        # does.  Nothing in THIS process has touched the GPU yet, and the ranks are children, not an exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     import torch
     dist = None
     if world > 1:
@@ -49,6 +62,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        world = dist.get_world_size()   # n_gpus is what the process group reports, not what the flag asked for
 
     import deft4j_amd as D
     import synth
@@ -137,9 +151,9 @@ def main():
                    "stream_bytes": len(stream), "blocks": st["n_blocks"], "tokens": st["n_tokens"],
                    "saved_bits": res["saved_bits"], "roundtrip_ok": bool(ok),
                    # BASELINE.json words the metric per GPU and adds the output-bit delta against the Java reference: the
-                   # value above is the whole job (== per GPU at N=1); the delta is 0 bits on every reference fixture
-                   # (tests/test_gpu_parity.py) and the round trip of this run's output is checked above
-                   "baseline_metric": baseline_metric, "value_per_gpu": round(value / world, 3), "output_bit_delta_vs_reference": 0},
+                   # value above is the whole job (== per GPU at N=1); the delta is MEASURED below on the cpu_baseline
+                   # sample (GPU output vs the oracle's output for the same stream) and added to this object
+                   "baseline_metric": baseline_metric, "value_per_gpu": round(value / world, 3)},
         "phases_ms": {k: round(st[k], 2) for k in ("ms_parse", "ms_optimise", "ms_merge", "ms_write", "ms_total")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -147,22 +161,49 @@ def main():
                      "avg_launch_ms": round(dur_s * 1000.0, 4), "kernel_ms_per_step": round(kern[dom], 3),
                      "parse_kernels_ms": round(st["ms_parse_kernels"], 3), "search_kernels_ms": round(st["ms_search_kernels"], 3)},
     }
+    parity_failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (single-thread C++ restatement; the reference's mode NONE is single-threaded,
-        # K/DeflateFilesContainer.java:22) on a bounded sample of the same workload.
+        # K/DeflateFilesContainer.java:22) on a bounded sample of the same workload.  Its output is also the parity
+        # reference of this run: the GPU optimises the same sample stream and the two outputs are compared.
         import oracle_lib as O
-        sample_n = 16 << 20
-        sraw = synth.reptext(sample_n, 0xD4F7)
+        sample_n = min(16 << 20, n)
+        sraw = raw[:sample_n]
         sstream = synth.deflate9(sraw)
         t0 = time.perf_counter()
-        O.optimise(sstream, bool(args.merge))
+        orc, oout, osaved, _, _ = O.optimise(sstream, bool(args.merge))
         cs = time.perf_counter() - t0
+        gb = D.Batch([sstream]).run(bool(args.merge))
+        gres = gb.result(0)
+        gout = gb.output(0)
+        gb.close()
+        obits = O.size_bits(oout if orc == 0 else sstream)
+        gbits = gres["size_bits_in"] - gres["saved_bits"]
+        identical = gout == (oout if orc == 0 else sstream) and gres["status"] == orc and gres["saved_bits"] == (osaved if orc == 0 else 0)
+        line["config"]["output_bit_delta_vs_reference"] = int(gbits - obits)
+        line["config"]["output_bytes_identical_to_oracle"] = bool(identical)
+        line["config"]["parity_sample"] = "first %d MiB of the timed input, re-deflated (zlib-9), merge=%s" % (sample_n >> 20, "on" if args.merge else "off")
+        parity_failed = not identical
         line["cpu_baseline"] = {"value": round(sample_n / 1e6 / cs, 4), "unit": "MB/s", "cores": 1, "kind": "port",
-                                "sample": "first 16 MiB of the same generator (seed 0xD4F7), zlib-9 stream, %.1f s of CPU" % cs}
+                                "sample": "first %d MiB of the same generator (seed 0xD4F7), zlib-9 stream, %.1f s of CPU" % (sample_n >> 20, cs)}
+        # all host cores, stream-parallel: one independent 2 MiB stream per core, the way the
+        # reference would be run over many files; ctypes releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        cores = min(os.cpu_count() or 1, 16)   # a one-GPU box's CPU share is 16 cores
+        part = 2 << 20
+        pieces = [synth.deflate9(raw[(k * part) % max(part, n - part):][:part]) for k in range(cores)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(lambda a: O.optimise(a, bool(args.merge)), pieces))
+        ca = time.perf_counter() - t0
+        line["cpu_baseline"]["all_cores"] = {"value": round(cores * part / 1e6 / ca, 4), "unit": "MB/s", "cores": cores,
+                                             "sample": "%d independent 2 MiB slices of the input, one oracle thread each, %.1f s" % (cores, ca)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed or not ok:
+        sys.exit("bench.py: the GPU output differs from the oracle's (or does not round-trip)")
 
 
 if __name__ == "__main__":

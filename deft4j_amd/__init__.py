@@ -75,6 +75,16 @@ def load_library(path=None):
     L.d4g_batch_destroy.argtypes = [ctypes.c_void_p]
     L.d4g_free.restype = None
     L.d4g_free.argtypes = [ctypes.c_void_p]
+    L.d4g_optimise_streams.restype = ctypes.c_int
+    L.d4g_optimise_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]
+    L.d4g_size_bits_fallback.restype = ctypes.c_int
+    L.d4g_size_bits_fallback.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int64)]
+    L.d4g_inflate.restype = ctypes.c_int
+    L.d4g_inflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
+                              ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                              ctypes.POINTER(ctypes.c_int32)]
     if path is None:
         _lib = L
     return L
@@ -201,11 +211,9 @@ class Deft:
             b.close()
 
     @staticmethod
-    def getSizeBitsFallback(deflateStream):
-        L = _need()
+    def getSizeBitsFallback(deflateStream, lib=None):
+        L = lib or _need()
         bits = ctypes.c_int64()
-        L.d4g_size_bits_fallback.restype = ctypes.c_int
-        L.d4g_size_bits_fallback.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int64)]
         rc = L.d4g_size_bits_fallback(bytes(deflateStream), len(deflateStream), ctypes.byref(bits))
         if rc != 0:
             raise RuntimeError(L.d4g_last_error().decode())
@@ -216,8 +224,9 @@ class DeflateStream:
     """Object API — B/deflate/DeflateStream.java (parse / optimise / getSizeBits / getUncompressedData / asBytes)."""
     DEFAULT_NAME = "unnamed stream"
 
-    def __init__(self, name=None):
+    def __init__(self, name=None, lib=None):
         self.name = name or self.DEFAULT_NAME
+        self._lib = lib
         self._data = None
         self._batch = None
         self._parsed = None
@@ -226,16 +235,10 @@ class DeflateStream:
         return self.name
 
     def parse(self, data):
-        """-> bool.  Device parse happens on first use; `consumed` gives the bytes DeflateStream.parse(InputStream) reads."""
+        """-> bool.  `consumed` gives the bytes DeflateStream.parse(InputStream) reads (K/GZFile.java:84 relies on it)."""
         self._data = bytes(data)
         self.close()
-        probe = Batch([self._data])
-        L = probe.L
-        L.d4g_inflate.restype = ctypes.c_int
-        L.d4g_inflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
-                                  ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
-                                  ctypes.POINTER(ctypes.c_int32)]
-        probe.close()
+        L = self._lib or _need()
         out = ctypes.c_void_p()
         ol = ctypes.c_size_t()
         co = ctypes.c_size_t()
@@ -258,18 +261,27 @@ class DeflateStream:
         if self._batch is not None:
             r = self._batch.result(0)
             return r["size_bits_in"] - r["saved_bits"]
-        return Deft.getSizeBitsFallback(self._data)
+        return Deft.getSizeBitsFallback(self._data, self._lib)
 
     def optimise(self, mergeBlocks=True):
         """-> bits saved (DeflateStream.optimise(boolean), :496)."""
         self.close()
-        self._batch = Batch([self._data]).run(mergeBlocks)
+        self._batch = Batch([self._data], lib=self._lib).run(mergeBlocks)
         return self._batch.result(0)["saved_bits"]
 
     def asBytes(self):
-        if self._batch is None:
-            self._batch = Batch([self._data]).run(False)
-        return self._batch.output(0)
+        """DeflateStream.asBytes() (:652) = write(): the stream as it stands.  Before optimise() that is the parsed
+        stream re-serialised unchanged: the bytes parse() consumed, with the padding bits of the last byte written as
+        zeros (DeflateStream.write :143 pads with zero bits)."""
+        if self._batch is not None:
+            return self._batch.output(0)
+        if self._parsed is None:
+            raise RuntimeError("asBytes() on a stream that did not parse")
+        out = bytearray(self._data[:self.consumed])
+        rem = Deft.getSizeBitsFallback(self._data, self._lib) % 8
+        if rem and out:
+            out[-1] &= (1 << rem) - 1
+        return bytes(out)
 
     def close(self):
         if self._batch is not None:

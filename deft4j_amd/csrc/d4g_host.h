@@ -67,13 +67,11 @@ static inline int lanes() {
 // (config 2, 332 blocks: 79 vs 87 ms).  D4G_EXEC=persistent|levels forces one; default switches at
 // D4G_PERSIST_MAX_BLOCKS active blocks.
 static inline int exec_persistent(int nActive = 0) {
-    static int mode = -1, maxBlocks = 128;
-    if (mode < 0) {
-        const char* t = getenv("D4G_EXEC");
-        mode = !t ? 2 : !strcmp(t, "levels") ? 0 : !strcmp(t, "persistent") ? 1 : 2;
-        const char* m = getenv("D4G_PERSIST_MAX_BLOCKS");
-        if (m) maxBlocks = atoi(m);
-    }
+    // read per call (not cached): the parity tests switch executors inside one process
+    const char* t = getenv("D4G_EXEC");
+    const int mode = !t ? 2 : !strcmp(t, "levels") ? 0 : !strcmp(t, "persistent") ? 1 : 2;
+    const char* m = getenv("D4G_PERSIST_MAX_BLOCKS");
+    const int maxBlocks = m ? atoi(m) : 128;
 #ifdef D4G_HOSTSIM
     return mode == 0 ? 0 : 1;
 #endif
@@ -314,6 +312,11 @@ struct Program {
         };
         for (auto& v : stateLevels) std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return cost(x) > cost(y); });
     }
+    void release() {
+        rt_free(dOps); rt_free(dLists); rt_free(dStateFlat); rt_free(dHdrFlat);
+        dOps = nullptr; dLists = nullptr; dStateFlat = nullptr; dHdrFlat = nullptr;
+        stateOff.clear(); hdrOff.clear(); wideOff.clear();
+    }
     void upload() {
         dOps = (D4GOp*)rt_malloc(ops.size() * sizeof(D4GOp));
         rt_h2d(dOps, ops.data(), ops.size() * sizeof(D4GOp));
@@ -382,11 +385,22 @@ struct Engine {  // per-process device objects shared by all batches
     long long* dOpStats = nullptr;
     uint32_t* dCrcTab = nullptr;   // [1024] slice-by-4 CRC-32 tables, then [32] x^(2^k) mod P
     int slotsPerBlock = 0, masksPerBlock = 0, maxOps = 0;
-    bool ready = false;
+    bool ready = false, built = false;
+    // d4g_shutdown: the device objects go back (a later d4g_init may pick another device)
+    void release() {
+        if (!ready) return;
+        progDyn.release(); progFixed.release();
+        rt_free(dHdrTables); rt_free(dErrors); rt_free(dOpStats); rt_free(dCrcTab);
+        dHdrTables = nullptr; dErrors = nullptr; dOpStats = nullptr; dCrcTab = nullptr;
+        ready = false;
+    }
     void init() {
         if (ready) return;
-        progDyn.build(false);
-        progFixed.build(true);
+        if (!built) {
+            progDyn.build(false);
+            progFixed.build(true);
+            built = true;
+        }
         if (getenv("D4G_DEBUG_PROGRAM"))
             fprintf(stderr, "program: %d ops requested, %zu emitted (%zu header searches over %zu distinct code-length sets), %d levels, %d slots, %d masks\n",
                     progDyn.nRequested, progDyn.ops.size(), (size_t)std::count_if(progDyn.ops.begin(), progDyn.ops.end(), [](const D4GOp& o) { return o.kind == OP_HDRSEARCH; }),
@@ -958,7 +972,7 @@ struct Batch {
                 rt_stream_wait(hsDone);
                 RT_LAUNCH(k_select, nA, state_block(), c, dResults);
                 stats.kernel_launches++;
-                stats.search_lanes = 1;
+                stats.search_lanes = std::max<int64_t>(stats.search_lanes, 1);
             } else {
             // Split the active blocks into groups, one stream lane each: the launch tail of one group's level
             // (a few long recode/tree ops) overlaps the other groups' levels.
@@ -1019,7 +1033,7 @@ struct Batch {
                 stats.kernel_launches++;
                 laneDone.emplace_back(new RtEvent());
                 laneDone.back()->record();
-                stats.search_lanes = G;
+                stats.search_lanes = std::max<int64_t>(stats.search_lanes, G);   // most lanes any round of the batch used
             }
             rt().cur = 0;
             for (auto& ev : laneDone) rt_stream_wait(*ev);

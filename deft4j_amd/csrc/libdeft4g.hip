@@ -19,6 +19,13 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 bool ready() { return rt().ready; }
+// HIP's current device is per thread: CompressionUtil's pool threads (and any rank with device != 0) must bind
+// the library's device before allocating or launching.  Called under g_mu at the top of every entry point.
+void bind_device() {
+#ifndef D4G_HOSTSIM
+    if (rt().ready && rt().device >= 0) RT_CHECK(hipSetDevice(rt().device));
+#endif
+}
 }  // namespace
 
 extern "C" {
@@ -33,6 +40,8 @@ int d4g_init(int device_index) {
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) return fail(D4G_ERR_NODEVICE, "no HIP device available (libdeft4g has no CPU fallback)");
         if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
+        if (rt().ready && rt().device != device_index)
+            return fail(D4G_ERR_ARG, "already initialised on device " + std::to_string(rt().device) + ": call d4g_shutdown() before selecting another device");
         RT_CHECK(hipSetDevice(device_index));
         for (int k = 0; k < RT_MAX_LANES; k++) {
             if (!rt().a[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().a[k], hipStreamNonBlocking));
@@ -51,16 +60,29 @@ int d4g_init(int device_index) {
 
 void d4g_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    rt().ready = false;
+    if (!rt().ready) return;
+    try {
+        bind_device();
+        rt_sync_all();
+        engine().release();
 #ifndef D4G_HOSTSIM
-    rt_pool_release();
+        rt_pool_release();
+        for (int k = 0; k < RT_MAX_LANES; k++) {
+            if (rt().a[k]) { (void)hipStreamDestroy(rt().a[k]); rt().a[k] = nullptr; }
+            if (rt().b[k]) { (void)hipStreamDestroy(rt().b[k]); rt().b[k] = nullptr; }
+        }
+        rt().device = -1;
 #endif
+    } catch (const std::exception&) {
+    }
+    rt().ready = false;
 }
 
 d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
     try {
+        bind_device();
         std::unique_ptr<d4g_batch> b(new d4g_batch());
         b->impl.create(n, in, in_len);
         return b.release();
@@ -75,6 +97,7 @@ int d4g_batch_run(d4g_batch* b, int merge_blocks) {
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
     try {
+        bind_device();
         b->impl.run(merge_blocks != 0);
         return D4G_OK;
     } catch (const std::exception& ex) {
@@ -103,6 +126,7 @@ int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
     size_t n = (size_t)((s.outBits + 7) / 8);
     if (cap < n) return fail(D4G_ERR_ARG, "output buffer too small");
     try {
+        bind_device();
         rt_d2h(dst, (const uint8_t*)(b->impl.dOut + s.outWordBase), n);
         return D4G_OK;
     } catch (const std::exception& ex) {
@@ -119,6 +143,7 @@ int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, siz
     if (!dst) return D4G_OK;
     if (cap < (size_t)s.nU) return fail(D4G_ERR_ARG, "output buffer too small");
     try {
+        bind_device();
         rt_d2h(dst, b->impl.dU + s.uBase, (size_t)s.nU);
         return D4G_OK;
     } catch (const std::exception& ex) {
@@ -131,6 +156,7 @@ int d4g_batch_parse(d4g_batch* b) {
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
     try {
+        bind_device();
         if (b->impl.ran) return fail(D4G_ERR_ARG, "batch already ran");
         b->impl.ran = true;
         engine().init();
@@ -147,6 +173,7 @@ int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
     try {
+        bind_device();
         b->impl.checksums();
         const D4GCsumOut& o = b->impl.csums[i];
         if (crc32) *crc32 = o.crc32;
@@ -166,30 +193,46 @@ int d4g_batch_stats(d4g_batch* b, d4g_stats* st) {
 
 void d4g_batch_destroy(d4g_batch* b) {
     std::lock_guard<std::mutex> lk(g_mu);
+    try { bind_device(); } catch (const std::exception&) {}
     delete b;
 }
 
 int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
                          size_t* out_len, int64_t* saved_bits, int32_t* status) {
-    if (!in || !in_len || !out || !out_len || !status) return fail(D4G_ERR_ARG, "null argument");
+    if (n && (!in || !in_len || !out || !out_len || !status)) return fail(D4G_ERR_ARG, "null argument");
+    // every result slot is defined whatever happens below: "keep the original" until a stream is known to have changed
+    for (size_t i = 0; i < n; i++) {
+        out[i] = nullptr;
+        out_len[i] = 0;
+        status[i] = D4G_STREAM_UNCHANGED;
+        if (saved_bits) saved_bits[i] = 0;
+    }
     d4g_batch* b = d4g_batch_create(n, in, in_len);
     if (!b) return D4G_ERR_RUNTIME;
     int rc = d4g_batch_run(b, merge_blocks);
-    if (rc == D4G_OK) {
-        for (size_t i = 0; i < n && rc == D4G_OK; i++) {
-            int64_t sv = 0;
-            size_t ol = 0;
-            d4g_batch_stream_result(b, i, &status[i], &sv, &ol, nullptr, nullptr);
-            if (saved_bits) saved_bits[i] = sv;
+    for (size_t i = 0; i < n && rc == D4G_OK; i++) {
+        int64_t sv = 0;
+        size_t ol = 0;
+        int32_t st = D4G_STREAM_UNCHANGED;
+        d4g_batch_stream_result(b, i, &st, &sv, &ol, nullptr, nullptr);
+        if (st == D4G_STREAM_CHANGED) {
+            out[i] = (uint8_t*)malloc(ol ? ol : 1);
+            if (!out[i]) { rc = fail(D4G_ERR_RUNTIME, "out of host memory"); break; }
+            rc = d4g_batch_copy_output(b, i, out[i], ol);
+            if (rc != D4G_OK) break;
+            out_len[i] = ol;
+        }
+        status[i] = st;
+        if (saved_bits) saved_bits[i] = sv;
+    }
+    if (rc != D4G_OK)   // all-or-nothing: a failed call hands back no buffers
+        for (size_t i = 0; i < n; i++) {
+            free(out[i]);
             out[i] = nullptr;
             out_len[i] = 0;
-            if (status[i] == D4G_STREAM_CHANGED) {
-                out[i] = (uint8_t*)malloc(ol ? ol : 1);
-                out_len[i] = ol;
-                rc = d4g_batch_copy_output(b, i, out[i], ol);
-            }
+            status[i] = D4G_STREAM_UNCHANGED;
+            if (saved_bits) saved_bits[i] = 0;
         }
-    }
     std::string keep = g_err;
     d4g_batch_destroy(b);
     g_err = keep;
@@ -206,6 +249,7 @@ int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         try {
+            bind_device();
             engine().init();
             b->impl.parse_probe();
             const Batch::PStream& o = b->impl.ps[0];
@@ -231,6 +275,7 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
     {
         std::lock_guard<std::mutex> lk(g_mu);
         try {
+            bind_device();
             engine().init();
             b->impl.parse_probe();
             b->impl.build_blocks(false, false);

@@ -42,6 +42,62 @@ def test_all_reference_fixture_pairs_bit_exact(D):
         b.close()
 
 
+@pytest.mark.parametrize("mode", ["levels", "persistent"])
+def test_fixture_pairs_under_each_executor(D, monkeypatch, mode):
+    """The candidate search has two executors (d4g_host.h exec_persistent): `persistent` work-queue kernels (default at
+    <= 128 active blocks) and one launch per program level (`levels`, the one bench.py's 332-block stream runs).
+    Both must reproduce all 30 reference pairs."""
+    monkeypatch.setenv("D4G_EXEC", mode)
+    for merge in (True, False):
+        pairs = [p for p in MAN["pairs"] if p["merge_blocks"] == merge]
+        ins = [rd(p["stem"] + ".in.deflate") for p in pairs]
+        b = D.Batch(ins).run(merge)
+        for i, p in enumerate(pairs):
+            assert b.result(i)["saved_bits"] == p["saved_bits"], (mode, p["stem"])
+            assert b.output(i) == rd(p["stem"] + ".out.deflate"), (mode, p["stem"])
+        b.close()
+
+
+def _oracle_many(ins, merge):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:   # ctypes releases the GIL
+        return list(ex.map(lambda a: O.optimise(a, merge), ins))
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_levels_executor_large_batch_vs_oracle(D, merge):
+    """More than 128 dynamic blocks in one batch, so the default executor choice is `levels` with two stream lanes
+    (the launch sequencing bench.py times): 28 x 1 MiB reptext members, every output byte-compared with the oracle."""
+    raws = [synth.reptext(1 << 20, 0x5EED + i) for i in range(28)]
+    ins = [synth.deflate9(r) for r in raws]
+    b = D.Batch(ins).run(merge)
+    st = b.stats()
+    assert st["n_blocks"] > 128 and st["search_lanes"] >= 2, st
+    want = _oracle_many(ins, merge)
+    for i, a in enumerate(ins):
+        rc, w, saved, _, _ = want[i]
+        r = b.result(i)
+        assert r["status"] == rc and r["saved_bits"] == saved, i
+        assert b.output(i) == (w if rc == 0 else a), i
+    b.close()
+
+
+def test_config2_full_size_vs_oracle(D):
+    """BASELINE config 2 at full size: 64 MiB reptext (seed 0xD4F7), zlib-9 raw deflate, one stream, mode NONE,
+    merge off — the exact input bench.py times — byte-compared with the oracle (about a minute of CPU)."""
+    raw = synth.reptext(64 << 20, 0xD4F7)
+    a = synth.deflate9(raw)
+    b = D.Batch([a]).run(False)
+    out = b.output(0)
+    r = b.result(0)
+    b.close()
+    rc, want, saved, _, _ = O.optimise(a, False)
+    assert rc == 0 and r["status"] == 0
+    assert r["saved_bits"] == saved
+    assert out == want
+    assert zlib.decompress(out, -15) == raw
+
+
 def test_deft_api_semantics(D):
     a = rd("asyoulik_asyoulik-zopfli.s00.in.deflate")
     out = D.Deft.optimiseDeflateStream(a)

@@ -46,7 +46,27 @@ def test_golden_pairs_in_the_emulator(sim, stem):
     b.close()
 
 
-def test_batch_of_synthetic_streams_matches_oracle(sim):
+def test_one_shot_abi_entry_points_in_the_emulator(sim):
+    """d4g_optimise_streams / d4g_size_bits_fallback / d4g_inflate (the functions the JNI shim binds) called
+    directly: changed, unchanged and malformed streams in one call, NULL-out contract, all result slots defined."""
+    import abi_calls
+    D, L = sim
+    good = rd("deflate-dynamic.parse.deflate")
+    streams = [rd("lz-twice-twice.s00.in.deflate"), rd("text.s00.in.deflate"), b"\x07garbage", b"", good[:len(good) // 2],
+               synth.make_stream(1200, 8), synth.deflate9(b"")]
+    for merge in (True, False):
+        kinds = abi_calls.check_one_shot_entry_points(L, O, streams, merge)
+        assert kinds == {0, 1, -1}
+    s = D.DeflateStream(lib=L)
+    a = rd("lz-twice-twice.s00.in.deflate")
+    assert s.parse(a + b"xyz") and s.consumed == len(a) and s.asBytes() == a
+    assert s.optimise() == MAN["lz-twice-twice.s00"]["saved_bits"] and s.asBytes() == rd("lz-twice-twice.s00.out.deflate")
+    s.close()
+
+
+@pytest.mark.parametrize("mode", ["levels", "persistent"])
+def test_batch_of_synthetic_streams_matches_oracle(sim, monkeypatch, mode):
+    monkeypatch.setenv("D4G_EXEC", mode)
     D, L = sim
     t = synth.reptext(6000, 11)
     c0 = zlib.compressobj(0, zlib.DEFLATED, -15)
