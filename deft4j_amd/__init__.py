@@ -29,12 +29,21 @@ class d4g_stats(ctypes.Structure):
                [("ms_search_kernels", ctypes.c_double), ("ms_parse_kernels", ctypes.c_double)] + \
                [(n, ctypes.c_int64) for n in ("scan_candidates", "scan_confirmed", "exact_probes", "jump_rounds")] + \
                [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64), ("state_tokens_per_round", ctypes.c_int64),
-                ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64), ("ms_checksum_kernels", ctypes.c_double)]
+                ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64), ("ms_checksum_kernels", ctypes.c_double),
+                ("ms_lz_sort", ctypes.c_double), ("ms_lz_parse", ctypes.c_double), ("ms_lz_emit", ctypes.c_double),
+                ("lz_parse_passes", ctypes.c_int64), ("lz_chunks_rerun", ctypes.c_int64), ("lz_symbols", ctypes.c_int64)]
 
+
+class d4g_encoder_spec(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_int32), ("encoder", ctypes.c_int32), ("strategy", ctypes.c_int32)]
+
+
+ENC_JVM, ENC_JZLIB = 0, 1                                   # D4G_ENC_*: JavaCompressor / JZLibCompressor
+STRATEGY_DEFAULT, STRATEGY_FILTERED, STRATEGY_HUFFMAN_ONLY = 0, 1, 2
 
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",
            "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_checksums", "d4g_batch_parse", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
-           "d4g_size_bits_fallback", "d4g_inflate", "d4g_free"]
+           "d4g_size_bits_fallback", "d4g_inflate", "d4g_free", "d4g_batch_create_encode", "d4g_batch_run_encode", "d4g_deflate_streams"]
 
 
 def load_library(path=None):
@@ -85,6 +94,14 @@ def load_library(path=None):
     L.d4g_inflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
                               ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
                               ctypes.POINTER(ctypes.c_int32)]
+    L.d4g_batch_create_encode.restype = ctypes.c_void_p
+    L.d4g_batch_create_encode.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t,
+                                          ctypes.POINTER(d4g_encoder_spec)]
+    L.d4g_batch_run_encode.restype = ctypes.c_int
+    L.d4g_batch_run_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.d4g_deflate_streams.restype = ctypes.c_int
+    L.d4g_deflate_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     if path is None:
         _lib = L
     return L
@@ -194,6 +211,49 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class EncodeBatch(Batch):
+    """Streams produced by the LZ77 encoder kernels (d4g_batch_create_encode): one output per (input, encoder, strategy)
+    spec — the Compressor objects of C/CompressionUtil.java:44-78.  run(optimise=False) leaves the encoder's output as it
+    is (SingleCompressor.compressSingle); optimise=True also applies Deft.optimiseDeflateStream to every output."""
+
+    def __init__(self, inputs, specs, lib=None):  # noqa: super().__init__ deliberately not called: a different constructor
+        self.L = lib or _need()
+        self.n = len(specs)
+        self._keep = [bytes(s) for s in inputs]
+        nin = len(self._keep)
+        arr = (ctypes.c_char_p * max(1, nin))(*self._keep)
+        lens = (ctypes.c_size_t * max(1, nin))(*[len(s) for s in self._keep])
+        sp = (d4g_encoder_spec * max(1, self.n))(*[d4g_encoder_spec(*t) for t in specs])
+        self.h = self.L.d4g_batch_create_encode(nin, arr, lens, self.n, sp)
+        if not self.h:
+            raise RuntimeError("d4g_batch_create_encode: " + self.L.d4g_last_error().decode())
+
+    def run(self, optimise=False, merge_blocks=True):
+        rc = self.L.d4g_batch_run_encode(self.h, 1 if optimise else 0, 1 if merge_blocks else 0)
+        if rc != 0:
+            raise RuntimeError("d4g_batch_run_encode: " + self.L.d4g_last_error().decode())
+        return self
+
+
+def deflate_streams(inputs, encoder=ENC_JVM, strategy=STRATEGY_DEFAULT, lib=None):
+    """SingleCompressor.compressSingle for every input (d4g_deflate_streams)."""
+    L = lib or _need()
+    n = len(inputs)
+    keep = [bytes(s) for s in inputs]
+    arr = (ctypes.c_char_p * max(1, n))(*keep)
+    lens = (ctypes.c_size_t * max(1, n))(*[len(s) for s in keep])
+    out = (ctypes.c_void_p * max(1, n))()
+    olen = (ctypes.c_size_t * max(1, n))()
+    rc = L.d4g_deflate_streams(n, arr, lens, encoder, strategy, out, olen)
+    if rc != 0:
+        raise RuntimeError("d4g_deflate_streams: " + L.d4g_last_error().decode())
+    res = []
+    for i in range(n):
+        res.append(ctypes.string_at(out[i], olen[i]))
+        L.d4g_free(out[i])
+    return res
 
 
 class Deft:

@@ -559,8 +559,8 @@ struct Batch {
     }
 
     // ---- parse: header scan -> block probes -> chain -> emit -> pointer jumping ----
-    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits, nRef; int firstBatch; };
-    struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; };
+    struct PBlock { int type, bfinal; i64 bitPos, endBit, nTok, uLen, sizeBits, nRef; int firstBatch; i64 refSpan = -1; };   // refSpan: records the block occupies in refs even when it is STORED (LZ77 front end)
+    struct PStream { int status = 0; std::vector<PBlock> blocks; i64 nTok = 0, nU = 0, consumed = 0, sizeBits = 0; i64 uBaseFixed = -1; };   // uBaseFixed: the decoded bytes already sit in U (LZ77 front end: the raw input)
     std::vector<PStream> ps;
     D4GStreamDesc* dStreams = nullptr;
     D4GChunkPool chunkPool = {nullptr, nullptr, 0};   // the probe's verified chunk starts, replayed by the emit pass
@@ -698,8 +698,13 @@ struct Batch {
         }
     }
 
-    // ---- device block table + steps 3-4 (emit tokens/states, resolve decoded bytes) ----
-    void build_blocks(bool merge, bool needSlots) {
+    // ---- device block table: host block lists, device descriptors and every per-block array, from `ps` ----
+    struct Layout {
+        std::vector<int32_t> realBlocks;   // device blocks that come straight from the parse (not merge arenas)
+        std::vector<D4GEmitIn> emits;
+        std::vector<D4GTokRange> ranges;
+    };
+    void layout_blocks(bool merge, bool needSlots, Layout& LY) {
         Engine& E = engine();
         size_t n = streams.size();
         slotsAlloc = needSlots ? E.slotsPerBlock : 1;
@@ -707,10 +712,10 @@ struct Batch {
         hBlocks.clear();
         gpuType.clear();
         i64 maskWordsTotal = 0, tokTot = 0, uTot = 0, refTot = 0, binMaskWords = 0, passMemoWords = 0;
-        std::vector<int32_t> realBlocks;   // device blocks that come straight from the parse (not merge arenas)
+        std::vector<int32_t>& realBlocks = LY.realBlocks;
         std::vector<D4GStreamDesc> sd(n);
-        std::vector<D4GEmitIn> emits;
-        std::vector<D4GTokRange> ranges;
+        std::vector<D4GEmitIn>& emits = LY.emits;
+        std::vector<D4GTokRange>& ranges = LY.ranges;
         auto add_block = [&](int stream, i64 tokStart, i64 tokCount, i64 refStart, i64 refCount, i64 uStart, i64 uLen, i64 maskWordsCap,
                              int type) {
             D4GBlock b;
@@ -748,13 +753,13 @@ struct Batch {
             s.nU = P.nU;
             s.tokBase = tokTot;
             s.refBase = refTot;
-            s.uBase = uTot;
-            sd[si].data = dIn + s.inOff;
+            s.uBase = P.uBaseFixed >= 0 ? P.uBaseFixed : uTot;
+            sd[si].data = dIn ? dIn + s.inOff : nullptr;
             sd[si].len = s.inLen;
-            sd[si].uBase = uTot;
+            sd[si].uBase = s.uBase;
             sd[si].uLen = P.nU;
             tokTot += P.nTok;
-            uTot += (P.nU + 15) & ~15LL;
+            if (P.uBaseFixed < 0) uTot += (P.nU + 15) & ~15LL;
             if (P.status != 0) continue;
             int nHuff = 0;
             i64 tpos = 0, upos = 0, rpos = 0;
@@ -794,7 +799,7 @@ struct Batch {
                 s.blocks.push_back(hb);
                 tpos += pb.nTok;
                 upos += pb.uLen;
-                rpos += hb.refCount;
+                rpos += pb.refSpan >= 0 ? pb.refSpan : hb.refCount;
                 stats.n_blocks++;
             }
             s.nRef = rpos;
@@ -809,13 +814,15 @@ struct Batch {
             }
         }
         size_t nb = hBlocks.size();
+        if (!dStreams) dStreams = (D4GStreamDesc*)rt_malloc(n * sizeof(D4GStreamDesc) + 16);
         rt_h2d(dStreams, sd.data(), n * sizeof(D4GStreamDesc));
         if (refTot >= (1LL << 32)) throw std::runtime_error("batch holds 2^32 or more back-references: split it");
-        dTok = (uint2*)rt_malloc((size_t)tokTot * 8 + 64);
-        dRefs = (uint4*)rt_malloc((size_t)refTot * 16 + 64);
-        dTokRef = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
-        dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
-        dSrc = (uint32_t*)rt_malloc((size_t)uTot * 4 + 64);
+        uTotal = uTot;
+        // (the LZ77 front end has filled tok / refs / tokRef / U already, with the same numbering)
+        if (!dTok) dTok = (uint2*)rt_malloc((size_t)tokTot * 8 + 64);
+        if (!dRefs) dRefs = (uint4*)rt_malloc((size_t)refTot * 16 + 64);
+        if (!dTokRef) dTokRef = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
+        if (!dU) dU = (uint8_t*)rt_malloc((size_t)uTot + 64);
         if (nb) {
             dBlocks = (D4GBlock*)rt_malloc(nb * sizeof(D4GBlock));
             rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
@@ -829,9 +836,9 @@ struct Batch {
             }
             dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
             dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
-            // mask 0 of every block starts empty (no back-reference expanded)
+            // mask 0 of every block starts empty (no back-reference expanded); the writer reads it even when no search runs
+            rt_memset(dMasks, 0, (size_t)maskWordsTotal * 8 + 64);   // one fill instead of one per block
             if (needSlots) {
-                rt_memset(dMasks, 0, (size_t)maskWordsTotal * 8);   // one fill instead of one per block
                 dBinStat = (uint32_t*)rt_malloc(nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
                 dBinMask = (uint64_t*)rt_malloc((size_t)binMaskWords * 8 + 64);
                 rt_memset(dBinStat, 0, nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
@@ -844,6 +851,18 @@ struct Batch {
                 rt_memset(dRcMemo, 0, nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
             }
         }
+    }
+
+    // ---- steps 3-5 of the parse: emit tokens/states, resolve decoded bytes, bin statistics ----
+    i64 uTotal = 0;
+    void build_blocks(bool merge, bool needSlots) {
+        Engine& E = engine();
+        size_t n = streams.size();
+        Layout LY;
+        layout_blocks(merge, needSlots, LY);
+        std::vector<D4GEmitIn>& emits = LY.emits;
+        std::vector<D4GTokRange>& ranges = LY.ranges;
+        dSrc = (uint32_t*)rt_malloc((size_t)uTotal * 4 + 64);
         RtEvent e0, e1;
         e0.record();
         if (!emits.empty()) {
@@ -886,24 +905,27 @@ struct Batch {
                 if (bad[i]) throw std::runtime_error("parse: back-reference before the start of stream (host check missed it)");
             rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged);
         }
-        // 5. static bin statistics of every block's back-reference records (the least-expensive pass works from them)
-        int32_t* dReal = nullptr;
-        if (needSlots && !realBlocks.empty()) {
-            dReal = (int32_t*)rt_malloc(realBlocks.size() * 4);
-            rt_h2d(dReal, realBlocks.data(), realBlocks.size() * 4);
-            D4GCtx c = make_ctx(E.progDyn, 0);
-            RT_LAUNCH(k_block_bins, realBlocks.size() * D4G_BINS_SPLIT, 256, c, dReal);
-            stats.kernel_launches++;
-        }
+        block_bins(LY.realBlocks, needSlots);
         e1.record();
         rt_sync();
         msParseKernels += rt_elapsed_ms(e0, e1);
         rt_free(dSrc);
         dSrc = nullptr;
-        rt_free(dReal);
         rt_free(chunkPool.batches); rt_free(chunkPool.next);
         chunkPool = {nullptr, nullptr, 0};
         check_device_errors();
+    }
+    // 5. static bin statistics of every block's back-reference records (the least-expensive pass works from them);
+    //    also fills in the records' first decoded bytes
+    void block_bins(const std::vector<int32_t>& realBlocks, bool needSlots) {
+        if (!needSlots || realBlocks.empty()) return;
+        int32_t* dReal = (int32_t*)rt_malloc(realBlocks.size() * 4);
+        rt_h2d(dReal, realBlocks.data(), realBlocks.size() * 4);
+        D4GCtx c = make_ctx(engine().progDyn, 0);
+        RT_LAUNCH(k_block_bins, realBlocks.size() * D4G_BINS_SPLIT, 256, c, dReal);
+        stats.kernel_launches++;
+        rt_sync();
+        rt_free(dReal);
     }
 
     // One optimiseBlock call on every block of `act` (device block indices): runs the program

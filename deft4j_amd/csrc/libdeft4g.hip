@@ -3,11 +3,13 @@
 #include <mutex>
 
 #include "d4g_host.h"
+#include "d4g_lz77_host.h"
 
 using namespace d4g;
 
 struct d4g_batch {
     Batch impl;
+    std::unique_ptr<LzFront> lz;   // set for batches made by d4g_batch_create_encode
 };
 
 namespace {
@@ -96,6 +98,7 @@ int d4g_batch_run(d4g_batch* b, int merge_blocks) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
+    if (b->lz) return fail(D4G_ERR_ARG, "encoder batch: use d4g_batch_run_encode");
     try {
         bind_device();
         b->impl.run(merge_blocks != 0);
@@ -103,6 +106,62 @@ int d4g_batch_run(d4g_batch* b, int merge_blocks) {
     } catch (const std::exception& ex) {
         return fail(D4G_ERR_RUNTIME, ex.what());
     }
+}
+
+d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const size_t* raw_len, size_t n_out,
+                                   const d4g_encoder_spec* spec) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
+    if ((n_in && (!raw || !raw_len)) || (n_out && !spec)) { fail(D4G_ERR_ARG, "null argument"); return nullptr; }
+    try {
+        bind_device();
+        static_assert(sizeof(LzSpec) == sizeof(d4g_encoder_spec), "spec layout");
+        std::unique_ptr<d4g_batch> b(new d4g_batch());
+        b->lz.reset(new LzFront(b->impl));
+        b->lz->create(n_in, raw, raw_len, n_out, (const LzSpec*)spec);
+        return b.release();
+    } catch (const std::exception& ex) {
+        fail(D4G_ERR_RUNTIME, ex.what());
+        return nullptr;
+    }
+}
+
+int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    if (!b || !b->lz) return fail(D4G_ERR_ARG, "not an encoder batch");
+    try {
+        bind_device();
+        b->lz->run(optimise != 0, merge_blocks != 0);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int encoder, int strategy, uint8_t** out,
+                        size_t* out_len) {
+    if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; }
+    std::vector<d4g_encoder_spec> sp(n);
+    for (size_t i = 0; i < n; i++) sp[i] = {(int32_t)i, encoder, strategy};
+    d4g_batch* b = d4g_batch_create_encode(n, raw, raw_len, n, sp.data());
+    if (!b) return D4G_ERR_RUNTIME;
+    int rc = d4g_batch_run_encode(b, 0, 0);
+    for (size_t i = 0; i < n && rc == D4G_OK; i++) {
+        size_t ol = 0;
+        d4g_batch_stream_result(b, i, nullptr, nullptr, &ol, nullptr, nullptr);
+        out[i] = (uint8_t*)malloc(ol ? ol : 1);
+        if (!out[i]) { rc = fail(D4G_ERR_RUNTIME, "out of host memory"); break; }
+        rc = d4g_batch_copy_output(b, i, out[i], ol);
+        out_len[i] = ol;
+    }
+    if (rc != D4G_OK)
+        for (size_t i = 0; i < n; i++) { free(out[i]); out[i] = nullptr; out_len[i] = 0; }
+    std::string keep = g_err;
+    d4g_batch_destroy(b);
+    g_err = keep;
+    return rc;
 }
 
 int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* saved_bits, size_t* out_len, size_t* consumed,

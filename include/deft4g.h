@@ -46,6 +46,9 @@ typedef struct d4g_stats {
     int64_t state_tokens_per_round, state_bytes_per_round; /* summed over k_exec_state_ops launches: tokens / decoded bytes of the blocks each launch covers */
     int64_t search_lanes;             /* block groups whose level sequences run concurrently (stream lanes) */
     double ms_checksum_kernels;       /* device time of the CRC-32 / Adler-32 kernels (d4g_batch_checksums) */
+    /* encoder front end (d4g_batch_create_encode): device time of the hash sort, the lazy parse and the block emit */
+    double ms_lz_sort, ms_lz_parse, ms_lz_emit;
+    int64_t lz_parse_passes, lz_chunks_rerun, lz_symbols;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.
@@ -76,6 +79,30 @@ int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler
 int d4g_batch_parse(d4g_batch* b);
 int d4g_batch_stats(d4g_batch* b, d4g_stats* st);
 void d4g_batch_destroy(d4g_batch* b);
+
+/* ---- encoder front end: the LZ77 compressors behind deft4j's recompress modes ----
+ * One d4g_encoder_spec = one output of one Compressor object in CompressionUtil.getCompressors
+ * (deft4j-compress/.../util/compression/CompressionUtil.java:44-78):
+ *   D4G_ENC_JVM    JavaCompressor   (JavaCompressor.java:36-49): java.util.zip.Deflater(BEST_COMPRESSION, nowrap) = zlib level 9
+ *   D4G_ENC_JZLIB  JZLibCompressor  (JZLibCompressor.java:29-41): jzlib 1.1.x level 9 (same algorithm, early block flush)
+ * with strategy DEFAULT / FILTERED / HUFFMAN_ONLY.  The batch's streams are the specs' outputs, in order; several specs
+ * may name the same input (its hash chains are built once).  run_encode(optimise = 0) leaves every stream exactly as the
+ * encoder emits it (SingleCompressor.compressSingle); optimise = 1 also runs Deft.optimiseDeflateStream on it
+ * (CompressorTask.java:29-35) without serialising and re-parsing the encoder's output.  Results come through
+ * d4g_batch_stream_result / d4g_batch_copy_output: size_bits_in = bit size of the encoder's own output, saved_bits = what
+ * the optimiser took off it. */
+#define D4G_ENC_JVM 0
+#define D4G_ENC_JZLIB 1
+#define D4G_STRATEGY_DEFAULT 0
+#define D4G_STRATEGY_FILTERED 1
+#define D4G_STRATEGY_HUFFMAN_ONLY 2
+typedef struct d4g_encoder_spec { int32_t input, encoder, strategy; } d4g_encoder_spec;
+d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const size_t* raw_len, size_t n_out,
+                                   const d4g_encoder_spec* spec);
+int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks);
+/* SingleCompressor.compressSingle for n inputs with one encoder setting: out[i] is always set (release with d4g_free) */
+int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int encoder, int strategy, uint8_t** out,
+                        size_t* out_len);
 
 /* ---- one-shot wrappers ----
  * Deft.optimiseDeflateStream for n streams: out[i]/out_len[i] are set only when status[i] ==

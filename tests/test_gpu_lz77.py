@@ -1,0 +1,108 @@
+"""Parity of the LZ77 encoder kernels on the GPU, through the C ABI: byte-identical to the
+reference-held JavaCompressor pair (asyoulik), to the committed zlib-1.2.11 golden vectors, to live Python zlib and to the
+oracle (oracle/zlib9_oracle.c) on seeded inputs — and, with optimise on, identical to running the optimiser on the
+encoder's serialised output (the reference's compress -> Deft.optimiseDeflateStream sequence, C/CompressorTask.java:29-35)."""
+import json
+import os
+import random
+import zlib
+
+import pytest
+
+import oracle_lib as O
+import synth
+import zl9_lib as Z
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STRATS = ((0, zlib.Z_DEFAULT_STRATEGY, "default"), (1, zlib.Z_FILTERED, "filtered"), (2, zlib.Z_HUFFMAN_ONLY, "huffman"))
+
+
+@pytest.fixture(scope="module")
+def D():
+    import deft4j_amd
+    deft4j_amd.init(0)
+    return deft4j_amd
+
+
+def rd(n):
+    return open(os.path.join(G, n), "rb").read()
+
+
+def zref(d, zs):
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 8, zs)
+    return c.compress(d) + c.flush()
+
+
+def test_reference_fixture_pair(D):
+    fix = rd("asyoulik_asyoulik-gzip.s00.in.deflate")          # payload of test/asyoulik/asyoulik-gzip.txt.gz
+    text = zlib.decompress(fix, -15)
+    assert D.deflate_streams([text], D.ENC_JVM, D.STRATEGY_DEFAULT)[0] == fix
+
+
+def test_golden_vectors(D):
+    man = json.load(open(os.path.join(G, "lz_manifest.json")))
+    datas = [rd("lz_%s.bin" % c["name"]) for c in man["cases"]]
+    for st, _, sname in STRATS:
+        outs = D.deflate_streams(datas, D.ENC_JVM, st)          # all cases in one device batch
+        for c, o in zip(man["cases"], outs):
+            assert o == rd("lz_%s.%s.deflate" % (c["name"], sname)), (c["name"], sname)
+
+
+def test_one_batch_many_specs_vs_zlib_and_oracle(D):
+    """Ragged inputs x three strategies in one batch (the hash sort of an input is shared by its specs)."""
+    rng = random.Random(11)
+    ins = [synth.reptext(n, 20 + i) for i, n in enumerate((1, 2, 3, 257, 2047, 2048, 2049, 32767, 32768, 32769, 65274, 65275, 65536, 200000, 1 << 20))]
+    ins += [b"", b"z" * 300000, bytes(rng.choice(b"ACGT") for _ in range(150000)), os.urandom(100000),
+            os.urandom(40000) + synth.reptext(90000, 3), bytes(rng.choice(b"ab") for _ in range(120000)),
+            synth.reptext(16383 * 4, 8)[:16383 * 3 + 5]]
+    specs = [(i, D.ENC_JVM, st) for i in range(len(ins)) for st, _, _ in STRATS]
+    b = D.EncodeBatch(ins, specs).run(False)
+    for k, (i, _, st) in enumerate(specs):
+        want = zref(ins[i], STRATS[st][1])
+        assert b.output(k) == want, (i, len(ins[i]), st)
+        assert b.result(k)["size_bits_in"] == O.size_bits(want)
+        if i % 4 == 0:
+            assert Z.deflate(ins[i], st, Z.ZLIB) == want
+    b.close()
+
+
+def test_exact_block_fill_edges(D):
+    """A block that the very last symbol fills: the literal deflate_slow's epilogue emits closes it as the last block,
+    a match (or deflate_huff's last literal) flushes it as a non-last block and an empty last block follows."""
+    lits = os.urandom(16383)
+    two = os.urandom(16382) + b"\x00" * 300
+    for d in (lits, lits + lits, two, os.urandom(16383 * 2 - 1) + b"abcabcabcabc"):
+        for st, zs, _ in STRATS:
+            assert D.deflate_streams([d], D.ENC_JVM, st)[0] == zref(d, zs), (len(d), st)
+
+
+def test_config_sized_stream(D):
+    """16 MiB of the config-2 generator: byte-identical to zlib level 9 (three strategies), and the parse converges in
+    a few passes."""
+    raw = synth.reptext(16 << 20, 0xD4F7)
+    b = D.EncodeBatch([raw], [(0, D.ENC_JVM, st) for st, _, _ in STRATS]).run(False)
+    st = b.stats()
+    for k, (_, zs, _) in enumerate(STRATS):
+        assert b.output(k) == zref(raw, zs), k
+    assert st["lz_parse_passes"] <= 8, st
+    b.close()
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_encode_then_optimise_equals_optimise_of_the_encoded_stream(D, merge):
+    """run_encode(optimise=1) hands the encoder's tokens and states straight to the candidate search.  The result must
+    be what the reference computes: Deft.optimiseDeflateStream(compressor.compress(data)) — checked against the oracle
+    run on zlib's bytes, and against the GPU's own parse-then-optimise path."""
+    ins = [synth.reptext(n, 40 + i) for i, n in enumerate((5000, 70000, 300000))] + [os.urandom(30000) + synth.reptext(50000, 2), b"k" * 50000, b""]
+    specs = [(i, D.ENC_JVM, st) for i in range(len(ins)) for st, _, _ in STRATS]
+    b = D.EncodeBatch(ins, specs).run(True, merge)
+    for k, (i, _, st) in enumerate(specs):
+        enc = zref(ins[i], STRATS[st][1])
+        rc, want, saved, _, _ = O.optimise(enc, merge)
+        r = b.result(k)
+        assert r["status"] == rc and r["saved_bits"] == saved, (i, st)
+        assert b.output(k) == (want if rc == 0 else enc), (i, st)
+        assert r["size_bits_in"] == O.size_bits(enc)
+    b.close()

@@ -171,3 +171,29 @@ def test_scan_prefilter_probe_find_every_dynamic_block(sim):
     assert b.decoded(0) == raw
     assert st["n_blocks"] == nblocks and st["scan_confirmed"] >= nblocks - 2 and st["exact_probes"] <= 2, st
     b.close()
+
+
+def test_lz77_encoder_in_the_emulator(sim):
+    """The LZ77 front end (hash sort, wave-wide chain search, speculative lazy parse, zlib's trees) in the emulator:
+    byte-identical to Python zlib level 9 for three strategies, and encode+optimise equals the oracle's optimise of
+    zlib's bytes."""
+    import random
+    D, L = sim
+    rng = random.Random(3)
+    ins = [b"", b"a", b"abcabcabcabc" * 30, synth.reptext(9000, 1), bytes(rng.randrange(256) for _ in range(5000)), b"\0" * 20000]
+    zs = (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY)
+    specs = [(i, D.ENC_JVM, st) for i in range(len(ins)) for st in range(3)]
+    b = D.EncodeBatch(ins, specs, lib=L).run(False)
+    for k, (i, _, st) in enumerate(specs):
+        c = zlib.compressobj(9, zlib.DEFLATED, -15, 8, zs[st])
+        assert b.output(k) == c.compress(ins[i]) + c.flush(), (i, st)
+    b.close()
+    b = D.EncodeBatch(ins, specs, lib=L).run(True, True)
+    for k, (i, _, st) in enumerate(specs):
+        c = zlib.compressobj(9, zlib.DEFLATED, -15, 8, zs[st])
+        enc = c.compress(ins[i]) + c.flush()
+        rc, want, saved, _, _ = O.optimise(enc, True)
+        r = b.result(k)
+        assert r["status"] == rc and r["saved_bits"] == saved, (i, st)
+        assert b.output(k) == (want if rc == 0 else enc), (i, st)
+    b.close()
