@@ -31,7 +31,10 @@ class d4g_stats(ctypes.Structure):
                [("ms_state_kernels", ctypes.c_double), ("state_launches", ctypes.c_int64), ("state_tokens_per_round", ctypes.c_int64),
                 ("state_bytes_per_round", ctypes.c_int64), ("search_lanes", ctypes.c_int64), ("ms_checksum_kernels", ctypes.c_double),
                 ("ms_lz_sort", ctypes.c_double), ("ms_lz_parse", ctypes.c_double), ("ms_lz_emit", ctypes.c_double),
-                ("lz_parse_passes", ctypes.c_int64), ("lz_chunks_rerun", ctypes.c_int64), ("lz_symbols", ctypes.c_int64)]
+                ("lz_parse_passes", ctypes.c_int64), ("lz_chunks_rerun", ctypes.c_int64), ("lz_symbols", ctypes.c_int64),
+                ("ms_recompress_encode", ctypes.c_double), ("ms_recompress_encode_front", ctypes.c_double),
+                ("ms_recompress_encode_search", ctypes.c_double), ("ms_recompress_reoptimise", ctypes.c_double),
+                ("recompress_outputs", ctypes.c_int64)]
 
 
 class d4g_encoder_spec(ctypes.Structure):
@@ -43,7 +46,8 @@ STRATEGY_DEFAULT, STRATEGY_FILTERED, STRATEGY_HUFFMAN_ONLY = 0, 1, 2
 
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",
            "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_checksums", "d4g_batch_parse", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
-           "d4g_size_bits_fallback", "d4g_inflate", "d4g_free", "d4g_batch_create_encode", "d4g_batch_run_encode", "d4g_deflate_streams"]
+           "d4g_size_bits_fallback", "d4g_inflate", "d4g_free", "d4g_batch_create_encode", "d4g_batch_run_encode", "d4g_deflate_streams",
+           "d4g_compress", "d4g_recompress_streams", "d4g_batch_run_recompress", "d4g_batch_recompress_result"]
 
 
 def load_library(path=None):
@@ -102,6 +106,17 @@ def load_library(path=None):
     L.d4g_deflate_streams.restype = ctypes.c_int
     L.d4g_deflate_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_compress.restype = ctypes.c_int
+    L.d4g_compress.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int32)]
+    L.d4g_batch_run_recompress.restype = ctypes.c_int
+    L.d4g_batch_run_recompress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.d4g_batch_recompress_result.restype = ctypes.c_int
+    L.d4g_batch_recompress_result.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    L.d4g_recompress_streams.restype = ctypes.c_int
+    L.d4g_recompress_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]
     if path is None:
         _lib = L
     return L
@@ -145,6 +160,20 @@ class Batch:
         if rc != 0:
             raise RuntimeError("d4g_batch_run: " + self.L.d4g_last_error().decode())
         return self
+
+    def run_recompress(self, mode=1, merge_blocks=True, iter=20):   # noqa: A002
+        """CMDUtil.optimise's per-stream loop on the resident streams (d4g_batch_run_recompress)."""
+        rc = self.L.d4g_batch_run_recompress(self.h, mode, iter, 1 if merge_blocks else 0)
+        if rc != 0:
+            raise RuntimeError("d4g_batch_run_recompress: " + self.L.d4g_last_error().decode())
+        return self
+
+    def recompress_result(self, i):
+        """-> (grafted, recompress_saved_bits)"""
+        g = ctypes.c_int32()
+        r = ctypes.c_int64()
+        self.L.d4g_batch_recompress_result(self.h, i, ctypes.byref(g), ctypes.byref(r))
+        return bool(g.value), r.value
 
     def result(self, i):
         """-> dict(status, saved_bits, out_len, consumed, size_bits_in)"""
@@ -253,6 +282,68 @@ def deflate_streams(inputs, encoder=ENC_JVM, strategy=STRATEGY_DEFAULT, lib=None
     for i in range(n):
         res.append(ctypes.string_at(out[i], olen[i]))
         L.d4g_free(out[i])
+    return res
+
+
+MODE_NONE, MODE_CHEAP, MODE_ZOPFLI, MODE_ZOPFLI_EXTENSIVE, MODE_ZOPFLI_VERY_EXTENSIVE = range(5)   # M/Optimise.java RecompressMode
+
+
+class CompressionUtil:
+    """C/CompressionUtil.java as CMDUtil configures it (M/CMDUtil.java:44-50): the compressor list of a recompress
+    mode, every output through Deft.optimiseDeflateStream, strict minimum by parsed bit size in list order."""
+
+    def __init__(self, mode=MODE_CHEAP, iter=20, mergeBlocks=True, lib=None):   # noqa: A002 (the reference's name)
+        self.mode, self.iter, self.mergeBlocks, self._lib = mode, iter, mergeBlocks, lib
+        self.last_winner = None
+
+    def compress_many(self, buffers):
+        L = self._lib or _need()
+        n = len(buffers)
+        keep = [bytes(b) for b in buffers]
+        arr = (ctypes.c_char_p * max(1, n))(*keep)
+        lens = (ctypes.c_size_t * max(1, n))(*[len(b) for b in keep])
+        out = (ctypes.c_void_p * max(1, n))()
+        olen = (ctypes.c_size_t * max(1, n))()
+        win = (ctypes.c_int32 * max(1, n))()
+        rc = L.d4g_compress(n, arr, lens, self.mode, self.iter, 1 if self.mergeBlocks else 0, out, olen, win)
+        if rc != 0:
+            raise IOError("Unable to compress data: " + L.d4g_last_error().decode())   # CompressionUtil.java:177-179
+        res = []
+        for i in range(n):
+            res.append(ctypes.string_at(out[i], olen[i]))
+            L.d4g_free(out[i])
+        self.last_winner = list(win[:n])
+        return res
+
+    def compress(self, uncompressedData, threaded=False):
+        """-> the smallest optimised stream (CompressionUtil.compress :106-182).  `threaded` is accepted and ignored:
+        the result is the list-order one, which the reference's threaded path only matches when no sizes tie."""
+        return self.compress_many([uncompressedData])[0]
+
+
+def recompress_streams(streams, mode=MODE_CHEAP, mergeBlocks=True, iter=20, lib=None):   # noqa: A002
+    """CMDUtil.optimise's per-stream work (M/CMDUtil.java:70-105) for a list of raw deflate streams.
+    -> list of dict(status, saved_bits, recompress_saved, out) — out is None unless status == 0 (changed)."""
+    L = lib or _need()
+    n = len(streams)
+    keep = [bytes(b) for b in streams]
+    arr = (ctypes.c_char_p * max(1, n))(*keep)
+    lens = (ctypes.c_size_t * max(1, n))(*[len(b) for b in keep])
+    out = (ctypes.c_void_p * max(1, n))()
+    olen = (ctypes.c_size_t * max(1, n))()
+    sv = (ctypes.c_int64 * max(1, n))()
+    rs = (ctypes.c_int64 * max(1, n))()
+    st = (ctypes.c_int32 * max(1, n))()
+    rc = L.d4g_recompress_streams(n, arr, lens, mode, iter, 1 if mergeBlocks else 0, out, olen, sv, rs, st)
+    if rc != 0:
+        raise RuntimeError("d4g_recompress_streams: " + L.d4g_last_error().decode())
+    res = []
+    for i in range(n):
+        data = None
+        if out[i]:
+            data = ctypes.string_at(out[i], olen[i])
+            L.d4g_free(out[i])
+        res.append(dict(status=st[i], saved_bits=sv[i], recompress_saved=rs[i], out=data))
     return res
 
 

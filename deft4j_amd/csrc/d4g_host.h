@@ -537,7 +537,8 @@ struct Batch {
         return c;
     }
 
-    void create(size_t n, const uint8_t* const* in, const size_t* len) {
+    // fromDevice: the `in` pointers are device addresses (another batch's outputs): chained stages stay in HBM
+    void create(size_t n, const uint8_t* const* in, const size_t* len, bool fromDevice = false) {
         memset(&stats, 0, sizeof(stats));
         double t0 = now_ms();
         streams.resize(n);
@@ -552,7 +553,10 @@ struct Batch {
         i64 total = off + D4G_INCH + 64;
         dIn = (uint8_t*)rt_malloc((size_t)total);
         rt_memset(dIn, 0, (size_t)total);
-        for (size_t i = 0; i < n; i++) rt_h2d(dIn + streams[i].inOff, in[i], len[i]);
+        for (size_t i = 0; i < n; i++) {
+            if (fromDevice) rt_d2d(dIn + streams[i].inOff, in[i], len[i]);
+            else rt_h2d(dIn + streams[i].inOff, in[i], len[i]);
+        }
         rt_sync();
         stats.n_streams = (i64)n;
         stats.ms_upload = now_ms() - t0;

@@ -18,7 +18,7 @@ struct LzFront {
     std::vector<i64> rawLen, rawU;
     explicit LzFront(Batch& b) : B(b) {}
 
-    void create(size_t nIn, const uint8_t* const* raw, const size_t* len, size_t nOut, const LzSpec* sp) {
+    void create(size_t nIn, const uint8_t* const* raw, const size_t* len, size_t nOut, const LzSpec* sp, bool fromDevice = false) {
         memset(&B.stats, 0, sizeof(B.stats));
         double t0 = now_ms();
         specs.assign(sp, sp + nOut);
@@ -37,7 +37,10 @@ struct LzFront {
                 throw std::runtime_error("bad encoder spec");
         B.dU = (uint8_t*)rt_malloc((size_t)off + 1024);
         rt_memset(B.dU, 0, (size_t)off + 1024);
-        for (size_t i = 0; i < nIn; i++) rt_h2d(B.dU + rawU[i], raw[i], len[i]);
+        for (size_t i = 0; i < nIn; i++) {
+            if (fromDevice) rt_d2d(B.dU + rawU[i], raw[i], len[i]);
+            else rt_h2d(B.dU + rawU[i], raw[i], len[i]);
+        }
         rt_sync();
         B.streams.resize(nOut);
         B.stats.n_streams = (i64)nOut;

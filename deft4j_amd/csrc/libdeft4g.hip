@@ -10,6 +10,17 @@ using namespace d4g;
 struct d4g_batch {
     Batch impl;
     std::unique_ptr<LzFront> lz;   // set for batches made by d4g_batch_create_encode
+    // d4g_batch_run_recompress: the re-optimised winners of the recompression (its own copy of their bytes) and which streams took them
+    std::unique_ptr<Batch> reopt;
+    std::vector<int> reoptIndex;       // stream -> index in reopt (-1: none)
+    std::vector<char> graft;
+    std::vector<int64_t> recompSaved;
+    // where stream i's final bytes live
+    const HStream& final_stream(size_t i, const Batch** owner) const {
+        if (i < graft.size() && graft[i]) { *owner = reopt.get(); return reopt->streams[reoptIndex[i]]; }
+        *owner = &impl;
+        return impl.streams[i];
+    }
 };
 
 namespace {
@@ -168,10 +179,13 @@ int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* sa
                             int64_t* size_bits_in) {
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     const HStream& s = b->impl.streams[i];
-    int st = s.status != 0 ? D4G_STREAM_PARSE_ERROR : (s.saved > 0 ? D4G_STREAM_CHANGED : D4G_STREAM_UNCHANGED);
+    const Batch* owner = nullptr;
+    const HStream& f = b->final_stream(i, &owner);
+    const bool grafted = owner != &b->impl;
+    int st = s.status != 0 ? D4G_STREAM_PARSE_ERROR : ((s.saved > 0 || grafted) ? D4G_STREAM_CHANGED : D4G_STREAM_UNCHANGED);
     if (status) *status = st;
     if (saved_bits) *saved_bits = s.status == 0 ? s.saved : 0;
-    if (out_len) *out_len = s.status == 0 ? (size_t)((s.outBits + 7) / 8) : 0;
+    if (out_len) *out_len = s.status == 0 ? (size_t)((f.outBits + 7) / 8) : 0;
     if (consumed) *consumed = (size_t)s.consumed;
     if (size_bits_in) *size_bits_in = s.status == 0 ? s.sizeBitsIn : -1;
     return D4G_OK;
@@ -180,13 +194,14 @@ int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* sa
 int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
-    const HStream& s = b->impl.streams[i];
-    if (s.status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
+    if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
+    const Batch* owner = nullptr;
+    const HStream& s = b->final_stream(i, &owner);
     size_t n = (size_t)((s.outBits + 7) / 8);
     if (cap < n) return fail(D4G_ERR_ARG, "output buffer too small");
     try {
         bind_device();
-        rt_d2h(dst, (const uint8_t*)(b->impl.dOut + s.outWordBase), n);
+        rt_d2h(dst, (const uint8_t*)(owner->dOut + s.outWordBase), n);
         return D4G_OK;
     } catch (const std::exception& ex) {
         return fail(D4G_ERR_RUNTIME, ex.what());
@@ -358,6 +373,215 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
 }
 
 void d4g_free(void* p) { free(p); }
+
+}  // extern "C"
+
+namespace {
+// compressor list of a recompress mode, in CompressionUtil.getCompressors order (C/CompressionUtil.java:44-78 with the
+// flags CMDUtil.java:44-50 derives from the mode)
+bool mode_specs(int mode, std::vector<LzSpec>& list, std::string& why) {
+    list.clear();
+    if (mode < D4G_MODE_CHEAP || mode > D4G_MODE_ZOPFLI_VERY_EXTENSIVE) { why = "mode out of range"; return false; }
+    if (mode >= D4G_MODE_ZOPFLI) { why = "this mode needs a Zopfli compressor (CafeUndZopfli / JZopfli), which is not built; only NONE and CHEAP are"; return false; }
+    for (int enc : {LZ_FLAVOR_ZLIB, LZ_FLAVOR_JZLIB})       // java (JVM) first, jzlib last (:51-75)
+        for (int st : {LZ_DEFAULT, LZ_FILTERED, LZ_HUFFMAN_ONLY}) list.push_back({0, enc, st});
+    return true;
+}
+
+// CompressionUtil.compress for inputs that may live in host or device memory.  Leaves the encoder batch alive (its
+// outputs are device resident) and reports the winner of every input.
+struct CompressRun {
+    std::unique_ptr<d4g_batch> enc;
+    std::vector<int> winner;       // output stream index of the winner per input
+    size_t perInput = 0;
+};
+void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, bool merge) {
+    std::vector<LzSpec> list;
+    std::string why;
+    if (!mode_specs(mode, list, why)) throw std::runtime_error(why);
+    R.perInput = list.size();
+    std::vector<LzSpec> specs;
+    for (size_t i = 0; i < n; i++)
+        for (LzSpec s : list) { s.input = (int32_t)i; specs.push_back(s); }
+    R.enc.reset(new d4g_batch());
+    R.enc->lz.reset(new LzFront(R.enc->impl));
+    R.enc->lz->create(n, raw, len, specs.size(), specs.data(), fromDevice);
+    R.enc->lz->run(true, merge);
+    R.winner.assign(n, -1);
+    for (size_t i = 0; i < n; i++) {
+        long long best = 0;
+        for (size_t k = 0; k < R.perInput; k++) {
+            const HStream& s = R.enc->impl.streams[i * R.perInput + k];
+            long long bits = s.sizeBitsIn - s.saved;            // Deft.getSizeBitsFallback of the optimised output
+            if (R.winner[i] < 0 || bits < best) { R.winner[i] = (int)(i * R.perInput + k); best = bits; }
+        }
+    }
+}
+uint8_t* copy_stream_out(Batch& b, size_t i, size_t* len) {
+    const HStream& s = b.streams[i];
+    size_t nb = (size_t)((s.outBits + 7) / 8);
+    uint8_t* p = (uint8_t*)malloc(nb ? nb : 1);
+    if (!p) throw std::runtime_error("out of host memory");
+    rt_d2h(p, (const uint8_t*)(b.dOut + s.outWordBase), nb);
+    *len = nb;
+    return p;
+}
+}  // namespace
+
+extern "C" {
+
+int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int mode, int iter, int merge_blocks, uint8_t** out,
+                 size_t* out_len, int32_t* winner) {
+    (void)iter;
+    if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; if (winner) winner[i] = -1; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    try {
+        bind_device();
+        std::vector<LzSpec> probe;
+        std::string why;
+        if (!mode_specs(mode, probe, why)) return fail(D4G_ERR_ARG, why);
+        CompressRun R;
+        compress_run(R, n, raw, raw_len, false, mode, merge_blocks != 0);
+        for (size_t i = 0; i < n; i++) {
+            out[i] = copy_stream_out(R.enc->impl, (size_t)R.winner[i], &out_len[i]);
+            if (winner) winner[i] = (int32_t)(R.winner[i] - (int)(i * R.perInput));
+        }
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        for (size_t i = 0; i < n; i++) { free(out[i]); out[i] = nullptr; out_len[i] = 0; }
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+// CMDUtil.optimise's per-stream loop on a batch made by d4g_batch_create (locked by the caller)
+static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
+    Batch& A = b->impl;
+    const size_t n = A.streams.size();
+    double t0 = now_ms();
+    A.run(merge);                                      // container.optimise(mergeBlocks) — CMDUtil.java:70
+    b->graft.assign(n, 0);
+    b->recompSaved.assign(n, 0);
+    b->reoptIndex.assign(n, -1);
+    std::vector<size_t> ok;
+    for (size_t i = 0; i < n; i++)
+        if (A.streams[i].status == 0) ok.push_back(i);
+    if (mode == D4G_MODE_NONE || ok.empty()) return;
+    // stream.getUncompressedData() -> compUtil.compress(uncompressed, true) — :83-84; the decoded bytes stay in HBM
+    std::vector<const uint8_t*> rp(ok.size());
+    std::vector<size_t> rl(ok.size());
+    for (size_t k = 0; k < ok.size(); k++) { rp[k] = A.dU + A.streams[ok[k]].uBase; rl[k] = (size_t)A.streams[ok[k]].nU; }
+    CompressRun R;
+    compress_run(R, ok.size(), rp.data(), rl.data(), true, mode, merge);
+    double t1 = now_ms();
+    // new DeflateStream().parse(recompressed); recompStream.optimise(mergeBlocks) — :85-89
+    std::vector<const uint8_t*> wp(ok.size());
+    std::vector<size_t> wl(ok.size());
+    for (size_t k = 0; k < ok.size(); k++) {
+        const HStream& w = R.enc->impl.streams[R.winner[k]];
+        wp[k] = (const uint8_t*)(R.enc->impl.dOut + w.outWordBase);
+        wl[k] = (size_t)((w.outBits + 7) / 8);
+    }
+    b->reopt.reset(new Batch());
+    b->reopt->create(ok.size(), wp.data(), wl.data(), true);
+    b->reopt->run(merge);
+    for (size_t k = 0; k < ok.size(); k++) {
+        const HStream& a = A.streams[ok[k]];
+        const HStream& c2 = b->reopt->streams[k];
+        b->reoptIndex[ok[k]] = (int)k;
+        if (c2.status != 0) continue;                  // recompStream.parse failed: the original stays (:88)
+        long long recompSize = c2.sizeBitsIn - c2.saved, originalSize = a.sizeBitsIn - a.saved;
+        if (recompSize < originalSize) {               // :94-98
+            b->graft[ok[k]] = 1;
+            b->recompSaved[ok[k]] = originalSize - recompSize;
+        }
+    }
+    const d4g_stats& es = R.enc->impl.stats;
+    A.stats.ms_lz_sort = es.ms_lz_sort; A.stats.ms_lz_parse = es.ms_lz_parse; A.stats.ms_lz_emit = es.ms_lz_emit;
+    A.stats.lz_parse_passes = es.lz_parse_passes; A.stats.lz_chunks_rerun = es.lz_chunks_rerun; A.stats.lz_symbols = es.lz_symbols;
+    A.stats.ms_recompress_encode = t1 - (t0 + A.stats.ms_total);
+    A.stats.ms_recompress_encode_front = es.ms_parse;
+    A.stats.ms_recompress_encode_search = es.ms_optimise + es.ms_merge;
+    A.stats.ms_recompress_reoptimise = now_ms() - t1;
+    A.stats.recompress_outputs = (int64_t)R.enc->impl.streams.size();
+    const d4g_stats* chained[2] = {&es, &b->reopt->stats};
+    for (const d4g_stats* o : chained) {   // the same kernels ran in the chained batches: one set of counters
+        A.stats.ms_state_kernels += o->ms_state_kernels; A.stats.state_launches += o->state_launches;
+        A.stats.state_tokens_per_round += o->state_tokens_per_round; A.stats.state_bytes_per_round += o->state_bytes_per_round;
+        A.stats.kernel_launches += o->kernel_launches; A.stats.rounds += o->rounds;
+        A.stats.ms_search_kernels += o->ms_search_kernels; A.stats.ms_parse_kernels += o->ms_parse_kernels;
+    }
+    A.stats.search_bytes_algorithmic += es.search_bytes_algorithmic + b->reopt->stats.search_bytes_algorithmic;
+}
+
+int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks) {
+    (void)iter;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    if (!b || b->lz) return fail(D4G_ERR_ARG, "not a batch of deflate streams");
+    try {
+        bind_device();
+        std::vector<LzSpec> probe;
+        std::string why;
+        if (mode != D4G_MODE_NONE && !mode_specs(mode, probe, why)) return fail(D4G_ERR_ARG, why);
+        run_recompress_locked(b, mode, merge_blocks != 0);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_batch_recompress_result(d4g_batch* b, size_t i, int32_t* grafted, int64_t* recompress_saved) {
+    if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
+    if (grafted) *grafted = i < b->graft.size() ? b->graft[i] : 0;
+    if (recompress_saved) *recompress_saved = i < b->recompSaved.size() ? b->recompSaved[i] : 0;
+    return D4G_OK;
+}
+
+int d4g_recompress_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int mode, int iter, int merge_blocks,
+                           uint8_t** out, size_t* out_len, int64_t* saved_bits, int64_t* recompress_saved, int32_t* status) {
+    if (n && (!in || !in_len || !out || !out_len || !status)) return fail(D4G_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n; i++) {
+        out[i] = nullptr; out_len[i] = 0; status[i] = D4G_STREAM_UNCHANGED;
+        if (saved_bits) saved_bits[i] = 0;
+        if (recompress_saved) recompress_saved[i] = 0;
+    }
+    d4g_batch* b = d4g_batch_create(n, in, in_len);
+    if (!b) return D4G_ERR_RUNTIME;
+    int rc = d4g_batch_run_recompress(b, mode, iter, merge_blocks);
+    for (size_t i = 0; i < n && rc == D4G_OK; i++) {
+        int64_t sv = 0, rs = 0;
+        size_t ol = 0;
+        int32_t st = D4G_STREAM_UNCHANGED;
+        d4g_batch_stream_result(b, i, &st, &sv, &ol, nullptr, nullptr);
+        d4g_batch_recompress_result(b, i, nullptr, &rs);
+        if (st == D4G_STREAM_CHANGED) {
+            out[i] = (uint8_t*)malloc(ol ? ol : 1);
+            if (!out[i]) { rc = fail(D4G_ERR_RUNTIME, "out of host memory"); break; }
+            rc = d4g_batch_copy_output(b, i, out[i], ol);
+            if (rc != D4G_OK) break;
+            out_len[i] = ol;
+        }
+        status[i] = st;
+        if (saved_bits) saved_bits[i] = sv;
+        if (recompress_saved) recompress_saved[i] = rs;
+    }
+    if (rc != D4G_OK)
+        for (size_t i = 0; i < n; i++) {
+            free(out[i]); out[i] = nullptr; out_len[i] = 0; status[i] = D4G_STREAM_UNCHANGED;
+            if (saved_bits) saved_bits[i] = 0;
+            if (recompress_saved) recompress_saved[i] = 0;
+        }
+    std::string keep = g_err;
+    d4g_batch_destroy(b);
+    g_err = keep;
+    return rc;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 #ifdef D4G_HOSTSIM
 // emulator builds only: the closed-form pack summary against the reference-shaped loop, every flag set and run length

@@ -49,6 +49,10 @@ typedef struct d4g_stats {
     /* encoder front end (d4g_batch_create_encode): device time of the hash sort, the lazy parse and the block emit */
     double ms_lz_sort, ms_lz_parse, ms_lz_emit;
     int64_t lz_parse_passes, lz_chunks_rerun, lz_symbols;
+    /* d4g_batch_run_recompress: wall clock of the encode + optimise of every compressor output (front = encoder kernels,
+     * search = candidate search on the encoder outputs) and of the re-parse + optimise of the winners */
+    double ms_recompress_encode, ms_recompress_encode_front, ms_recompress_encode_search, ms_recompress_reoptimise;
+    int64_t recompress_outputs;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.
@@ -103,6 +107,36 @@ int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks);
 /* SingleCompressor.compressSingle for n inputs with one encoder setting: out[i] is always set (release with d4g_free) */
 int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int encoder, int strategy, uint8_t** out,
                         size_t* out_len);
+
+/* ---- recompress modes (deft4j-cmd/.../cmd/CMDUtil.java:44-50, Optimise.java `--mode`) ----
+ * mode = ordinal of RecompressMode: the compressor list CompressionUtil.getCompressors builds for it (:44-78), in list
+ * order JVM{DEFAULT, FILTERED, HUFFMAN_ONLY}, [JZopfli], [CafeUndZopfli], JZlib{DEFAULT, FILTERED, HUFFMAN_ONLY}.
+ * Only the zlib-family compressors are built: modes that need a Zopfli compressor fail with D4G_ERR_ARG (no silent
+ * substitute).  `iter` (Zopfli iterations) is accepted for signature parity and unused by the built modes. */
+#define D4G_MODE_NONE 0
+#define D4G_MODE_CHEAP 1
+#define D4G_MODE_ZOPFLI 2
+#define D4G_MODE_ZOPFLI_EXTENSIVE 3
+#define D4G_MODE_ZOPFLI_VERY_EXTENSIVE 4
+/* CompressionUtil.compress(uncompressedData, threaded) (CompressionUtil.java:106-182) with useDeft = compareDeft = true
+ * as CMDUtil configures it: every compressor output goes through Deft.optimiseDeflateStream(out, merge_blocks) and the
+ * strict minimum by parsed bit size wins, ties to the earlier compressor in list order (the non-threaded loop :144-168 —
+ * the threaded one takes completion order, which is not deterministic).  out[i] is always set; winner[i] (optional) is
+ * the index of the winning output in list order. */
+int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int mode, int iter, int merge_blocks, uint8_t** out,
+                 size_t* out_len, int32_t* winner);
+/* CMDUtil.optimise for n raw deflate streams (CMDUtil.java:70-105): optimise; then, mode > NONE, recompress the decoded
+ * bytes (d4g_compress), re-parse and optimise the winner, and take it iff its bit size is strictly smaller than the
+ * optimised original's.  status[i]: D4G_STREAM_CHANGED (out[i] set: the optimised original or the grafted recompression),
+ * D4G_STREAM_UNCHANGED (out[i] = NULL: keep the input), D4G_STREAM_PARSE_ERROR.  saved_bits[i] = DeflateStream.optimise's
+ * return for the original; recompress_saved[i] = originalSize - recompSize when grafted, else 0. */
+/* The same on a batch made by d4g_batch_create (inputs resident in HBM): afterwards d4g_batch_stream_result /
+ * d4g_batch_copy_output describe the FINAL stream (the grafted recompression where it won); d4g_batch_recompress_result
+ * tells which streams were grafted and by how many bits. */
+int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks);
+int d4g_batch_recompress_result(d4g_batch* b, size_t i, int32_t* grafted, int64_t* recompress_saved);
+int d4g_recompress_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int mode, int iter, int merge_blocks,
+                           uint8_t** out, size_t* out_len, int64_t* saved_bits, int64_t* recompress_saved, int32_t* status);
 
 /* ---- one-shot wrappers ----
  * Deft.optimiseDeflateStream for n streams: out[i]/out_len[i] are set only when status[i] ==

@@ -106,3 +106,61 @@ def test_encode_then_optimise_equals_optimise_of_the_encoded_stream(D, merge):
         assert b.output(k) == (want if rc == 0 else enc), (i, st)
         assert r["size_bits_in"] == O.size_bits(enc)
     b.close()
+
+
+def test_jzlib_flavour_vs_oracle(D):
+    """The jzlib compressor family (early block flush at 8192 symbols; PARITY UNPINNED — no jzlib here): byte-identical
+    to the oracle's restatement and valid streams."""
+    ins = [synth.reptext(n, 60 + i) for i, n in enumerate((100, 70000, 400000, 1 << 20))] + [os.urandom(50000), b"", synth.reptext(16383 * 2, 3)]
+    specs = [(i, D.ENC_JZLIB, st) for i in range(len(ins)) for st, _, _ in STRATS]
+    b = D.EncodeBatch(ins, specs).run(False)
+    for k, (i, _, st) in enumerate(specs):
+        out = b.output(k)
+        assert out == Z.deflate(ins[i], st, Z.JZLIB), (i, st)
+        assert zlib.decompress(out, -15) == ins[i]
+    b.close()
+
+
+@pytest.mark.parametrize("merge", [True, False])
+def test_mode_cheap_on_the_asyoulik_text(D, merge):
+    """CompressionUtil.compress, mode CHEAP (six compressors, each output optimised, strict minimum in list order —
+    C/CompressionUtil.java:44-78,144-168) on the reference's own text, and CMDUtil's recompress-compare-graft loop
+    (M/CMDUtil.java:70-105) on the reference's fixture streams, against the same orchestration over the oracles."""
+    import oracle_compose as OC
+    text = zlib.decompress(rd("asyoulik_asyoulik-gzip.s00.in.deflate"), -15)
+    cu = D.CompressionUtil(D.MODE_CHEAP, mergeBlocks=merge)
+    out = cu.compress(text)
+    want, win = OC.compress(text, merge)
+    assert out == want and cu.last_winner == [win]
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15)
+    streams = [rd("asyoulik_asyoulik-gzip.s00.in.deflate"), rd("asyoulik_asyoulik-zopfli.s00.in.deflate"), c1.compress(text) + c1.flush(),
+               b"\x07junk", rd("lz-twice-twice.s00.in.deflate")]
+    res = D.recompress_streams(streams, D.MODE_CHEAP, merge)
+    for a, r in zip(streams, res):
+        assert r == OC.recompress(a, merge), len(a)
+    assert res[2]["recompress_saved"] > 0 and res[1]["recompress_saved"] == 0      # zlib-1 loses to zlib-9; zopfli's stream stays
+
+
+def test_mode_cheap_batch_of_members(D):
+    """Config-3-shaped batch, scaled (24 x 256 KiB gzip members, mode CHEAP) through the resident-batch entry point:
+    every final stream equals the oracle orchestration's, and round-trips."""
+    import oracle_compose as OC
+    from concurrent.futures import ThreadPoolExecutor
+    raws = [synth.reptext(256 << 10, 0xD4F7 + i) for i in range(24)]
+    c6 = [zlib.compressobj(6, zlib.DEFLATED, -15) for _ in raws]
+    ins = [synth.deflate9(r) if i % 2 == 0 else c.compress(r) + c.flush() for i, (r, c) in enumerate(zip(raws, c6))]
+    b = D.Batch(ins).run_recompress(D.MODE_CHEAP, True)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        want = list(ex.map(lambda a: OC.recompress(a, True), ins))
+    ngraft = 0
+    for i, a in enumerate(ins):
+        r = b.result(i)
+        g, rs = b.recompress_result(i)
+        w = want[i]
+        assert r["status"] == w["status"] and r["saved_bits"] == w["saved_bits"] and rs == w["recompress_saved"], i
+        final = b.output(i) if r["status"] == 0 else a
+        assert final == (w["out"] if w["status"] == 0 else a), i
+        assert zlib.decompress(final, -15) == raws[i]
+        ngraft += g
+    assert ngraft >= 12          # every zlib-6 member is beaten by its recompression
+    b.close()

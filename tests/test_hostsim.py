@@ -197,3 +197,28 @@ def test_lz77_encoder_in_the_emulator(sim):
         assert r["status"] == rc and r["saved_bits"] == saved, (i, st)
         assert b.output(k) == (want if rc == 0 else enc), (i, st)
     b.close()
+
+
+def test_recompress_modes_in_the_emulator(sim):
+    """CompressionUtil.compress (mode CHEAP: six zlib-family compressors, each output optimised, strict minimum in list
+    order) and CMDUtil's recompress-compare-graft loop against the same orchestration over the oracles."""
+    import oracle_compose as OC
+    D, L = sim
+    raws = [synth.reptext(2500, 21), bytes(range(256)) * 4, b"", b"ab" * 900]
+    for merge in (True, False):
+        cu = D.CompressionUtil(D.MODE_CHEAP, mergeBlocks=merge, lib=L)
+        outs = cu.compress_many(raws)
+        for r, o, w in zip(raws, outs, cu.last_winner):
+            want, win = OC.compress(r, merge)
+            assert o == want and w == win, (len(r), merge)
+            assert zlib.decompress(o, -15) == r
+    # streams: a weakly compressed one (recompression wins), a zlib-9 one, a malformed one
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15)
+    streams = [c1.compress(raws[0]) + c1.flush(), synth.deflate9(raws[3]), b"\x07junk", synth.deflate9(b"")]
+    for merge in (True, False):
+        res = D.recompress_streams(streams, D.MODE_CHEAP, merge, lib=L)
+        for a, r in zip(streams, res):
+            assert r == OC.recompress(a, merge), (len(a), merge)
+    assert res[0]["recompress_saved"] > 0
+    with pytest.raises(IOError):
+        D.CompressionUtil(D.MODE_ZOPFLI, lib=L).compress(b"abc")      # needs a Zopfli compressor: loud failure, no substitute
