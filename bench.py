@@ -23,6 +23,186 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def _gen_member(seed):
+    import synth
+    raw = synth.reptext(1 << 20, seed)
+    return raw, synth.deflate9(raw)
+
+
+def bench_config3(args, rank, world, dist, tdev, D, synth, torch):
+    """BASELINE config 3: `--members` independent 1 MiB gzip members per GPU, mode CHEAP, merge on (the CLI default,
+    M/Optimise.java:33-34).  A step = CMDUtil.optimise's per-stream work for the whole batch (M/CMDUtil.java:70-105):
+    optimise every member, recompress its decoded bytes with the six zlib-family compressors (each output optimised),
+    re-parse + optimise the winner, graft it where smaller, and recompute the gzip trailer (CRC-32 / ISIZE)."""
+    import zlib
+    from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    members = args.members
+    seeds = [0xD4F7 + rank * members + i for i in range(members)]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        gen = list(ex.map(_gen_member, seeds, chunksize=8))
+    raws = [g[0] for g in gen]
+    streams = [g[1] for g in gen]
+    n_in = sum(len(r) for r in raws)
+    merge = True
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    total = args.warmup + args.steps
+
+    def step(b):
+        b.run_recompress(D.MODE_CHEAP, merge)
+        return b.checksums(0)      # trailer values of every member are computed in one device pass
+
+    for _ in range(args.warmup):
+        b = D.Batch(streams)
+        step(b)
+        b.close()
+    batches = [D.Batch(streams) for _ in range(args.steps)]   # uploads: inputs resident before timing
+    barrier()
+    t0 = time.perf_counter()
+    for b in batches:
+        step(b)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    last = batches[-1]
+    st = last.stats()
+    outs, grafted, saved, rsaved = [], 0, 0, 0
+    for i in range(members):
+        r = last.result(i)
+        g, rs = last.recompress_result(i)
+        outs.append(last.output(i) if r["status"] == 0 else streams[i])
+        grafted += g
+        saved += r["saved_bits"]
+        rsaved += rs
+    crc0 = last.checksums(0)
+    ok = all(zlib.decompress(o, -15) == r for o, r in zip(outs[:32], raws[:32])) and crc0[0] == (zlib.crc32(raws[0]) & 0xffffffff)
+    for b in batches:
+        b.close()
+    if dist is not None:
+        mine = torch.tensor([sum(len(s) for s in streams), sum(len(o) for o in outs), saved + rsaved], device=tdev, dtype=torch.int64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)    # the path's only exchange: sizes to rank 0 (RCCL over xGMI)
+    ms_step = elapsed * 1000.0 / args.steps
+    value = (n_in * world / 1e6) / (elapsed / args.steps)
+    launches = max(1, st["state_launches"])
+    n_tok = st["state_tokens_per_round"] / launches
+    n_u = st["state_bytes_per_round"] / launches
+    alg = int(8 * n_tok + min(n_u, 48 * n_tok))
+    dur_s = st["ms_state_kernels"] / 1000.0 / launches
+    achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
+    line = {
+        "metric": "input MB/s on gzip-member optimise, mode CHEAP", "value": round(value, 3), "unit": "MB/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%d x 1 MiB synthetic repetitive-text gzip members per GPU (zlib-9), mode=CHEAP, merge=on" % members,
+                   "members": members, "grafted": grafted, "saved_bits": saved, "recompress_saved_bits": rsaved,
+                   "compressor_outputs_searched": st["recompress_outputs"], "huffman_only_outputs_pruned_by_entropy_bound": st["recompress_outputs_pruned"],
+                   "roundtrip_ok": bool(ok), "value_per_gpu": round(value / world, 3)},
+        "phases_ms": {"optimise_originals": round(st["ms_total"], 2), "encode_and_search_outputs": round(st["ms_recompress_encode"], 2),
+                      "encoder_front_end": round(st["ms_recompress_encode_front"], 2), "search_of_outputs": round(st["ms_recompress_encode_search"], 2),
+                      "reoptimise_winners": round(st["ms_recompress_reoptimise"], 2),
+                      "lz_sort_kernels": round(st["ms_lz_sort"], 2), "lz_parse_kernels": round(st["ms_lz_parse"], 2), "lz_emit_kernels": round(st["ms_lz_emit"], 2),
+                      "lz_parse_passes": st["lz_parse_passes"], "lz_chunks_rerun": st["lz_chunks_rerun"]},
+        "roofline": {"bound": "hbm", "kernel": "k_exec_state_ops", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+                     "launches_per_step": launches, "avg_launch_ms": round(dur_s * 1000.0, 4),
+                     # SURVEY.md §8d whole-path figure: C_in + U + C_out, plus U + C_out_k per compressor pass
+                     "path_algorithmic_bytes": int(st["search_bytes_algorithmic"]),
+                     "path_achieved_GBs": round(st["search_bytes_algorithmic"] / (elapsed / args.steps) / 1e9, 3)},
+    }
+    parity_failed = False
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_compose as OC
+        k = min(4, members)
+        t0 = time.perf_counter()
+        OC.recompress(streams[0], merge)
+        c1 = time.perf_counter() - t0
+        with ThreadPoolExecutor(max_workers=k) as ex:
+            want = list(ex.map(lambda a: OC.recompress(a, merge), streams[:k]))
+        identical = all((outs[i] == (w["out"] if w["status"] == 0 else streams[i])) for i, w in enumerate(want))
+        line["config"]["output_bytes_identical_to_oracle"] = bool(identical)
+        line["config"]["parity_sample"] = "first %d members against the oracle orchestration (zlib-9 / jzlib oracles + optimiser oracle)" % k
+        parity_failed = not identical
+        line["cpu_baseline"] = {"value": round(len(raws[0]) / 1e6 / c1, 4), "unit": "MB/s", "cores": 1, "kind": "port",
+                                "sample": "one member (1 MiB) through the same orchestration over the oracles, %.1f s of CPU" % c1}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if parity_failed or not ok:
+        sys.exit("bench.py: the GPU output differs from the oracle's (or does not round-trip)")
+
+
+def _gen_mixed(i):
+    import synth
+    return synth.mixed_stream(i)
+
+
+def bench_config5(args, rank, world, dist, tdev, D, synth, torch):
+    """BASELINE config 5: --total-mib of mixed PNG-IDAT-like / gzip-member streams, mode NONE, merge on, sharded over the
+    GPUs at stream granularity (deft4j_amd/shard.py: LPT partition, no data-path collective, sizes combined on every rank
+    and outputs sent to rank 0 only).  Strong scaling: the job is fixed, every rank generates and holds only its shard."""
+    import zlib
+    from concurrent.futures import ProcessPoolExecutor
+    from deft4j_amd import shard
+    specs, tot = [], 0
+    while tot < (args.total_mib << 20):
+        kind, n = synth.mixed_spec(len(specs))
+        specs.append((kind, n))
+        tot += n
+    sizes = [n for _, n in specs]                   # the partition works on uncompressed sizes (known without generating)
+    mine = shard.lpt_partition(sizes, world)[rank]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        gen = dict(zip(mine, ex.map(_gen_mixed, mine, chunksize=2)))
+    streams = {i: g[2] for i, g in gen.items()}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        return shard.optimise_sharded(sizes, lambda i: streams[i], True, lambda ss: D.Batch(ss), dist=dist, device=tdev,
+                                      batch_bytes=1 << 30)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        total_saved, outs, _ = res
+        ok = True
+        for i in mine[:8]:                          # rank 0 holds the originals of its own shard only
+            o = outs[i] if outs[i] is not None else streams[i]
+            ok = ok and zlib.decompress(o, -15) == gen[i][1]
+        value = (tot / 1e6) / (elapsed / args.steps)
+        line = {"metric": "input MB/s on raw-deflate optimise (mode NONE), mixed streams sharded over the GPUs", "value": round(value, 3),
+                "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1000.0 / args.steps, 3),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "%d MiB of mixed PNG-IDAT-like (1-16 MiB) and 1 MiB text streams, zlib-9, mode=NONE, merge=on, stream-sharded" % args.total_mib,
+                           "streams": len(specs), "idat_streams": sum(1 for k, _ in specs if k == "idat"), "saved_bits": int(total_saved),
+                           "changed_streams": sum(1 for o in outs if o is not None), "roundtrip_ok": bool(ok), "value_per_gpu": round(value / world, 3)},
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -30,6 +210,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mib", type=int, default=64, help="uncompressed MiB per stream (64 = BASELINE config 2)")
     ap.add_argument("--merge", type=int, default=0)
+    ap.add_argument("--total-mib", type=int, default=8192, help="config5: uncompressed MiB of the whole job (strong scaling)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
+                    help="config2 (default, BASELINE.json's headline): one 64 MiB stream per GPU, mode NONE; "
+                         "config3: --members x 1 MiB gzip members per GPU, mode CHEAP (recompress + graft); "
+                         "config5: --total-mib of mixed PNG-IDAT-like / gzip streams sharded over the GPUs, mode NONE")
+    ap.add_argument("--members", type=int, default=1024, help="config3: members per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (rehearsal: several ranks on one GPU)")
@@ -68,6 +254,11 @@ def main():
     import synth
     D.init(local if args.device is None else args.device)
     tdev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
+
+    if args.workload == "config3":
+        return bench_config3(args, rank, world, dist, tdev, D, synth, torch)
+    if args.workload == "config5":
+        return bench_config5(args, rank, world, dist, tdev, D, synth, torch)
 
     # --- workload: one independent stream per rank (per-file sharding) ---
     n = args.mib << 20

@@ -34,7 +34,7 @@ class d4g_stats(ctypes.Structure):
                 ("lz_parse_passes", ctypes.c_int64), ("lz_chunks_rerun", ctypes.c_int64), ("lz_symbols", ctypes.c_int64),
                 ("ms_recompress_encode", ctypes.c_double), ("ms_recompress_encode_front", ctypes.c_double),
                 ("ms_recompress_encode_search", ctypes.c_double), ("ms_recompress_reoptimise", ctypes.c_double),
-                ("recompress_outputs", ctypes.c_int64)]
+                ("recompress_outputs", ctypes.c_int64), ("recompress_outputs_pruned", ctypes.c_int64)]
 
 
 class d4g_encoder_spec(ctypes.Structure):

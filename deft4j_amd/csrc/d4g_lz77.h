@@ -28,6 +28,8 @@
 //                bit packer (k_write) take over without a re-parse.
 // All integer / byte work; bound by LDS latency and VALU issue, not HBM.
 #pragma once
+#include <cmath>
+
 #include "d4g_device.h"
 
 #define LZ_SORT_BLOCK 32768
@@ -820,4 +822,25 @@ __global__ void k_lz_place_states(const D4GState* tmp, const long long* dstIdx, 
     const uint32_t* s = (const uint32_t*)(tmp + b);
     uint32_t* d = (uint32_t*)(states + dstIdx[b]);
     for (int i = threadIdx.x; i < (int)(sizeof(D4GState) / 4); i += blockDim.x) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lz_entropy_bound: a lower bound on what ANY all-literal encoding of an input can cost — the sum, over the
+// 16383-byte slices a HUFFMAN_ONLY compressor cuts it into, of the slice's zeroth-order entropy.  The optimiser never
+// creates a back-reference, and merging blocks or storing them only raises that sum, so a HUFFMAN_ONLY candidate whose
+// bound already exceeds the best optimised DEFAULT / FILTERED candidate cannot win CompressionUtil's strict minimum:
+// it is then not optimised at all (the winner and its bytes are unaffected).  One workgroup per slice.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LzBoundJob { const uint8_t* data; int32_t len, input; };
+__global__ void __launch_bounds__(256) k_lz_entropy_bound(const LzBoundJob* jobs, double* perInput) {
+    __shared__ unsigned hist[256];
+    const LzBoundJob J = jobs[blockIdx.x];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < J.len; i += 256) atomicAdd(&hist[J.data[i]], 1u);
+    __syncthreads();
+    const unsigned f = hist[threadIdx.x];
+    double v = f ? (double)f * log2((double)J.len / (double)f) : 0.0;
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0 && v > 0.0) atomicAdd(&perInput[J.input], v);
 }

@@ -388,32 +388,147 @@ bool mode_specs(int mode, std::vector<LzSpec>& list, std::string& why) {
     return true;
 }
 
-// CompressionUtil.compress for inputs that may live in host or device memory.  Leaves the encoder batch alive (its
-// outputs are device resident) and reports the winner of every input.
+// CompressionUtil.compress for inputs that live in host or device memory.  Inputs are processed in groups sized to the
+// device memory the candidate search needs (every block owns ~1.6 MB of candidate states); the winners' bytes are kept
+// in one device buffer.
 struct CompressRun {
-    std::unique_ptr<d4g_batch> enc;
-    std::vector<int> winner;       // output stream index of the winner per input
+    std::vector<int> winner;             // index in list order, per input
+    std::vector<long long> bits;         // its parsed bit size
+    std::vector<size_t> off, len;        // its bytes in dWin
+    uint8_t* dWin = nullptr;
+    size_t used = 0;
     size_t perInput = 0;
+    d4g_stats agg;
+    int64_t outputsOptimised = 0, outputsPruned = 0;
+    CompressRun() { memset(&agg, 0, sizeof(agg)); }
+    ~CompressRun() { rt_free(dWin); }
 };
+void add_stats(d4g_stats& a, const d4g_stats& o) {
+    a.ms_lz_sort += o.ms_lz_sort; a.ms_lz_parse += o.ms_lz_parse; a.ms_lz_emit += o.ms_lz_emit;
+    a.lz_parse_passes += o.lz_parse_passes; a.lz_chunks_rerun += o.lz_chunks_rerun; a.lz_symbols += o.lz_symbols;
+    a.ms_parse += o.ms_parse; a.ms_optimise += o.ms_optimise; a.ms_merge += o.ms_merge; a.ms_write += o.ms_write;
+    a.ms_state_kernels += o.ms_state_kernels; a.state_launches += o.state_launches;
+    a.state_tokens_per_round += o.state_tokens_per_round; a.state_bytes_per_round += o.state_bytes_per_round;
+    a.kernel_launches += o.kernel_launches; a.rounds += o.rounds; a.n_blocks += o.n_blocks; a.n_tokens += o.n_tokens;
+    a.ms_search_kernels += o.ms_search_kernels; a.ms_parse_kernels += o.ms_parse_kernels;
+    a.search_bytes_algorithmic += o.search_bytes_algorithmic;
+}
+std::unique_ptr<d4g_batch> encode_batch(size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, const std::vector<LzSpec>& specs,
+                                        bool merge) {
+    std::unique_ptr<d4g_batch> e(new d4g_batch());
+    e->lz.reset(new LzFront(e->impl));
+    e->lz->create(n, raw, len, specs.size(), specs.data(), fromDevice);
+    e->lz->run(true, merge);
+    return e;
+}
+// one group of inputs [i0, i1)
+void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* raw, const size_t* len, bool fromDevice,
+                    const std::vector<LzSpec>& list, bool merge) {
+    const size_t n = i1 - i0;
+    // stage 1: every compressor output that can hold back-references
+    std::vector<int> lzIdx, hIdx;   // list positions
+    for (size_t k = 0; k < list.size(); k++) (list[k].strategy == LZ_HUFFMAN_ONLY ? hIdx : lzIdx).push_back((int)k);
+    std::vector<LzSpec> specs;
+    for (size_t i = 0; i < n; i++)
+        for (int k : lzIdx) { LzSpec s = list[k]; s.input = (int32_t)i; specs.push_back(s); }
+    std::unique_ptr<d4g_batch> e1 = encode_batch(n, raw + i0, len + i0, fromDevice, specs, merge);
+    add_stats(R.agg, e1->impl.stats);
+    R.outputsOptimised += (int64_t)specs.size();
+    struct Best { long long bits = 0; int listIdx = -1; const Batch* owner = nullptr; int stream = -1; };
+    std::vector<Best> best(n);
+    auto offer = [&](size_t i, int listIdx, const Batch* owner, int stream) {
+        const HStream& s = owner->streams[stream];
+        long long bits = s.sizeBitsIn - s.saved;              // Deft.getSizeBitsFallback of the optimised output
+        Best& b = best[i];
+        if (b.listIdx < 0 || bits < b.bits || (bits == b.bits && listIdx < b.listIdx)) { b.bits = bits; b.listIdx = listIdx; b.owner = owner; b.stream = stream; }
+    };
+    for (size_t i = 0; i < n; i++)
+        for (size_t k = 0; k < lzIdx.size(); k++) offer(i, lzIdx[k], &e1->impl, (int)(i * lzIdx.size() + k));
+    // stage 2: the HUFFMAN_ONLY outputs, unless their entropy bound already loses
+    std::unique_ptr<d4g_batch> e2;
+    if (!hIdx.empty()) {
+        std::vector<LzBoundJob> jobs;
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* d = e1->impl.dU + e1->lz->rawU[i];
+            for (long long p = 0; p < e1->lz->rawLen[i]; p += LZ_SYMS_PER_BLOCK)
+                jobs.push_back({d + p, (int32_t)std::min<long long>(LZ_SYMS_PER_BLOCK, e1->lz->rawLen[i] - p), (int32_t)i});
+        }
+        std::vector<double> lb(n, 0.0);
+        if (!jobs.empty()) {
+            LzBoundJob* dJ = (LzBoundJob*)rt_malloc(jobs.size() * sizeof(LzBoundJob));
+            double* dLb = (double*)rt_malloc(n * 8 + 16);
+            rt_h2d(dJ, jobs.data(), jobs.size() * sizeof(LzBoundJob));
+            rt_memset(dLb, 0, n * 8);
+            RT_LAUNCH(k_lz_entropy_bound, jobs.size(), 256, dJ, dLb);
+            rt_d2h(lb.data(), dLb, n * 8);
+            rt_free(dJ); rt_free(dLb);
+        }
+        std::vector<size_t> need;
+        for (size_t i = 0; i < n; i++) {
+            double bound = lb[i] * (1.0 - 1e-9) - 1.0;       // rounding of the sum can only have raised it by less than this
+            if (bound > (double)best[i].bits) R.outputsPruned += (int64_t)hIdx.size();
+            else need.push_back(i);
+        }
+        if (!need.empty()) {
+            std::vector<const uint8_t*> rp(need.size());
+            std::vector<size_t> rl(need.size());
+            std::vector<LzSpec> sp2;
+            for (size_t q = 0; q < need.size(); q++) {
+                rp[q] = e1->impl.dU + e1->lz->rawU[need[q]];
+                rl[q] = (size_t)e1->lz->rawLen[need[q]];
+                for (int k : hIdx) { LzSpec s = list[k]; s.input = (int32_t)q; sp2.push_back(s); }
+            }
+            e2 = encode_batch(need.size(), rp.data(), rl.data(), true, sp2, merge);
+            add_stats(R.agg, e2->impl.stats);
+            R.outputsOptimised += (int64_t)sp2.size();
+            for (size_t q = 0; q < need.size(); q++)
+                for (size_t k = 0; k < hIdx.size(); k++) offer(need[q], hIdx[k], &e2->impl, (int)(q * hIdx.size() + k));
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        const Best& b = best[i];
+        const HStream& w = b.owner->streams[b.stream];
+        size_t nb = (size_t)((w.outBits + 7) / 8);
+        R.winner[i0 + i] = b.listIdx;
+        R.bits[i0 + i] = b.bits;
+        R.off[i0 + i] = R.used;
+        R.len[i0 + i] = nb;
+        rt_d2d(R.dWin + R.used, (const uint8_t*)(b.owner->dOut + w.outWordBase), nb);
+        R.used += (nb + 15) & ~(size_t)15;
+    }
+    rt_sync();
+}
 void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, bool merge) {
     std::vector<LzSpec> list;
     std::string why;
     if (!mode_specs(mode, list, why)) throw std::runtime_error(why);
     R.perInput = list.size();
-    std::vector<LzSpec> specs;
-    for (size_t i = 0; i < n; i++)
-        for (LzSpec s : list) { s.input = (int32_t)i; specs.push_back(s); }
-    R.enc.reset(new d4g_batch());
-    R.enc->lz.reset(new LzFront(R.enc->impl));
-    R.enc->lz->create(n, raw, len, specs.size(), specs.data(), fromDevice);
-    R.enc->lz->run(true, merge);
-    R.winner.assign(n, -1);
-    for (size_t i = 0; i < n; i++) {
-        long long best = 0;
-        for (size_t k = 0; k < R.perInput; k++) {
-            const HStream& s = R.enc->impl.streams[i * R.perInput + k];
-            long long bits = s.sizeBitsIn - s.saved;            // Deft.getSizeBitsFallback of the optimised output
-            if (R.winner[i] < 0 || bits < best) { R.winner[i] = (int)(i * R.perInput + k); best = bits; }
+    R.winner.assign(n, -1); R.bits.assign(n, 0); R.off.assign(n, 0); R.len.assign(n, 0);
+    size_t cap = 64;
+    for (size_t i = 0; i < n; i++) cap += len[i] + len[i] / 512 + 96;   // a deflate stream never exceeds its input by more than this
+    R.dWin = (uint8_t*)rt_malloc(cap);
+    // group size: the candidate search keeps ~1.6 MB of states per block; estimate >= 3 bytes per symbol and let an
+    // out-of-memory failure halve the group
+    const long long budget = env_int("D4G_GROUP_BLOCKS", 12000);
+    size_t i0 = 0;
+    long long shrink = 1;
+    while (i0 < n) {
+        size_t i1 = i0;
+        long long est = 0;
+        while (i1 < n) {
+            long long e = 4 * ((long long)len[i1] / (3LL * LZ_SYMS_PER_BLOCK) + 2);
+            if (i1 > i0 && (est + e) * shrink > budget) break;
+            est += e;
+            i1++;
+        }
+        try {
+            size_t usedBefore = R.used;
+            (void)usedBefore;
+            compress_group(R, i0, i1, raw, len, fromDevice, list, merge);
+            i0 = i1;
+        } catch (const std::runtime_error& ex) {
+            if (strstr(ex.what(), "hipMalloc") && i1 - i0 > 1) { shrink *= 2; continue; }   // group too large for the device: retry smaller
+            throw;
         }
     }
 }
@@ -445,8 +560,11 @@ int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int
         CompressRun R;
         compress_run(R, n, raw, raw_len, false, mode, merge_blocks != 0);
         for (size_t i = 0; i < n; i++) {
-            out[i] = copy_stream_out(R.enc->impl, (size_t)R.winner[i], &out_len[i]);
-            if (winner) winner[i] = (int32_t)(R.winner[i] - (int)(i * R.perInput));
+            out[i] = (uint8_t*)malloc(R.len[i] ? R.len[i] : 1);
+            if (!out[i]) throw std::runtime_error("out of host memory");
+            rt_d2h(out[i], R.dWin + R.off[i], R.len[i]);
+            out_len[i] = R.len[i];
+            if (winner) winner[i] = (int32_t)R.winner[i];
         }
         return D4G_OK;
     } catch (const std::exception& ex) {
@@ -478,11 +596,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
     // new DeflateStream().parse(recompressed); recompStream.optimise(mergeBlocks) — :85-89
     std::vector<const uint8_t*> wp(ok.size());
     std::vector<size_t> wl(ok.size());
-    for (size_t k = 0; k < ok.size(); k++) {
-        const HStream& w = R.enc->impl.streams[R.winner[k]];
-        wp[k] = (const uint8_t*)(R.enc->impl.dOut + w.outWordBase);
-        wl[k] = (size_t)((w.outBits + 7) / 8);
-    }
+    for (size_t k = 0; k < ok.size(); k++) { wp[k] = R.dWin + R.off[k]; wl[k] = R.len[k]; }
     b->reopt.reset(new Batch());
     b->reopt->create(ok.size(), wp.data(), wl.data(), true);
     b->reopt->run(merge);
@@ -497,14 +611,15 @@ static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
             b->recompSaved[ok[k]] = originalSize - recompSize;
         }
     }
-    const d4g_stats& es = R.enc->impl.stats;
+    const d4g_stats& es = R.agg;
     A.stats.ms_lz_sort = es.ms_lz_sort; A.stats.ms_lz_parse = es.ms_lz_parse; A.stats.ms_lz_emit = es.ms_lz_emit;
     A.stats.lz_parse_passes = es.lz_parse_passes; A.stats.lz_chunks_rerun = es.lz_chunks_rerun; A.stats.lz_symbols = es.lz_symbols;
     A.stats.ms_recompress_encode = t1 - (t0 + A.stats.ms_total);
     A.stats.ms_recompress_encode_front = es.ms_parse;
     A.stats.ms_recompress_encode_search = es.ms_optimise + es.ms_merge;
     A.stats.ms_recompress_reoptimise = now_ms() - t1;
-    A.stats.recompress_outputs = (int64_t)R.enc->impl.streams.size();
+    A.stats.recompress_outputs = R.outputsOptimised;
+    A.stats.recompress_outputs_pruned = R.outputsPruned;
     const d4g_stats* chained[2] = {&es, &b->reopt->stats};
     for (const d4g_stats* o : chained) {   // the same kernels ran in the chained batches: one set of counters
         A.stats.ms_state_kernels += o->ms_state_kernels; A.stats.state_launches += o->state_launches;

@@ -1,10 +1,13 @@
 """Multi-GPU sharding of independent DEFLATE streams.
 
-The reference iterates streams sequentially with no shared state (K/DeflateFilesContainer.java:22);
-here stream i goes to one rank (one process per GPU), every rank runs the whole hot path on its
-shard with no data-path collective, and the only exchange is the final gather of
-(status, saved_bits, out_len) and of the variable-length outputs to rank 0 — RCCL over xGMI when the
-process group is `nccl`, `gloo` in the CPU tests.
+The reference iterates streams sequentially with no shared state (K/DeflateFilesContainer.java:22); here stream i goes
+to one rank (one process per GPU), every rank runs the whole hot path on its shard with no data-path collective, and the
+only exchange is at the end: the per-stream (status, saved_bits, out_len) table is combined on every rank and the
+variable-length outputs travel to rank 0 only — grouped point-to-point sends, so over xGMI rank 0 receives on its seven
+links concurrently.  RCCL when the process group is `nccl`, `gloo` in the CPU tests.
+
+A rank only ever materialises the streams of its own shard: callers pass the sizes of all streams (what the LPT
+partition needs) and a `load(i)` function.
 """
 import torch
 
@@ -22,50 +25,77 @@ def lpt_partition(sizes, world):
     return [sorted(s) for s in shards]
 
 
-def optimise_sharded(streams, merge_blocks, make_batch, dist=None, device="cpu"):
-    """Every rank calls this with the same `streams`.  `make_batch(list_of_bytes)` returns an object with
-    run(merge) / result(i) / output(i) / close() (deft4j_amd.Batch).  Rank 0 gets
-    (total_saved, outputs, per_stream_saved); other ranks get None."""
+def _chunks(idx, sizes, budget):
+    """split a shard into sub-batches of at most `budget` compressed bytes (device memory stays bounded)"""
+    cur, tot = [], 0
+    for i in idx:
+        if cur and tot + sizes[i] > budget:
+            yield cur
+            cur, tot = [], 0
+        cur.append(i)
+        tot += sizes[i]
+    if cur:
+        yield cur
+
+
+def optimise_sharded(sizes, load, merge_blocks, make_batch, dist=None, device="cpu", batch_bytes=64 << 20, run=None):
+    """Every rank calls this with the same `sizes`; `load(i)` returns stream i's bytes and is only called for streams of
+    the caller's shard.  `make_batch(list_of_bytes)` returns an object with run(merge) / result(i) / output(i) / close()
+    (deft4j_amd.Batch); `run(batch)` overrides the default batch.run(merge_blocks) (e.g. a recompress mode).
+    Rank 0 gets (total_saved, outputs, per_stream_saved) with outputs[i] = the new bytes or None (unchanged / did not
+    parse: the caller keeps its original); other ranks get None."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    shards = lpt_partition([len(s) for s in streams], world)
+    n = len(sizes)
+    shards = lpt_partition(list(sizes), world)
     mine = shards[rank]
-    meta = torch.zeros((len(streams), 3), dtype=torch.int64)
+    meta = torch.zeros((n, 3), dtype=torch.int64)   # status, saved_bits, out_len (0: keep the original)
     outs = {}
-    if mine:
-        b = make_batch([streams[i] for i in mine]).run(merge_blocks)
-        for k, i in enumerate(mine):
+    for sub in _chunks(mine, sizes, batch_bytes):
+        b = make_batch([load(i) for i in sub])
+        if run is not None:
+            run(b)
+        else:
+            b.run(merge_blocks)
+        for k, i in enumerate(sub):
             r = b.result(k)
-            o = b.output(k) if r["status"] >= 0 else streams[i]
-            outs[i] = o
             meta[i, 0] = r["status"]
-            meta[i, 1] = r["saved_bits"] if r["status"] >= 0 else 0
-            meta[i, 2] = len(o)
+            if r["status"] == 0:
+                o = b.output(k)
+                outs[i] = o
+                meta[i, 1] = r["saved_bits"]
+                meta[i, 2] = len(o)
         b.close()
     if dist is None or world == 1:
-        return int(meta[:, 1].sum()), [outs[i] for i in range(len(streams))], meta[:, 1].tolist()
+        return int(meta[:, 1].sum()), [outs.get(i) for i in range(n)], meta[:, 1].tolist()
+    # (status, saved_bits, out_len) of every stream on every rank: each row is written by exactly one rank
     meta = meta.to(device)
-    dist.all_reduce(meta, op=dist.ReduceOp.SUM)          # each row is written by exactly one rank
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM)
     meta = meta.cpu()
-    # variable-length outputs: pad every rank's concatenation to the longest and all-gather
-    blob = b"".join(outs[i] for i in mine)
-    lens = torch.tensor([len(blob)], dtype=torch.int64, device=device)
-    dist.all_reduce(lens, op=dist.ReduceOp.MAX)
-    cap = max(1, int(lens.item()))
-    buf = torch.zeros(cap, dtype=torch.uint8)
-    if blob:
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-    buf = buf.to(device)
-    gathered = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf)
+    # variable-length outputs -> rank 0 only, one message per rank, all in flight together
     if rank != 0:
+        blob = b"".join(outs[i] for i in mine if i in outs)
+        if blob:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0)]):
+                w.wait()
         return None
-    result = [None] * len(streams)
-    for r in range(world):
-        data = gathered[r].cpu().numpy().tobytes()
+    bufs, ops = {}, []
+    for r in range(1, world):
+        nbytes = int(sum(int(meta[i, 2]) for i in shards[r]))
+        if nbytes:
+            bufs[r] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    result = [outs.get(i) for i in range(n)]
+    for r, buf in bufs.items():
+        data = buf.cpu().numpy().tobytes()
         off = 0
         for i in shards[r]:
-            n = int(meta[i, 2])
-            result[i] = data[off:off + n]
-            off += n
+            ln = int(meta[i, 2])
+            if ln:
+                result[i] = data[off:off + ln]
+                off += ln
     return int(meta[:, 1].sum()), result, meta[:, 1].tolist()

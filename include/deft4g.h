@@ -52,7 +52,8 @@ typedef struct d4g_stats {
     /* d4g_batch_run_recompress: wall clock of the encode + optimise of every compressor output (front = encoder kernels,
      * search = candidate search on the encoder outputs) and of the re-parse + optimise of the winners */
     double ms_recompress_encode, ms_recompress_encode_front, ms_recompress_encode_search, ms_recompress_reoptimise;
-    int64_t recompress_outputs;
+    int64_t recompress_outputs;         /* compressor outputs that went through the candidate search */
+    int64_t recompress_outputs_pruned;  /* HUFFMAN_ONLY outputs whose entropy bound already lost: not searched */
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

@@ -40,3 +40,40 @@ def deflate9(data, strategy=zlib.Z_DEFAULT_STRATEGY):
 
 def make_stream(n, seed=0xD4F7):
     return deflate9(reptext(n, seed))
+
+
+def pngidat(n, seed=0x1DA7, width=1024):
+    """PNG-IDAT-like bytes: rows of `width` RGB pixels, each row = one filter byte (1 = Sub)
+    followed by the Sub-filtered samples of smooth gradients plus a little noise.  Returns n bytes (whole rows, truncated)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    row = 1 + 3 * width
+    rows = (n + row - 1) // row
+    y = np.arange(rows, dtype=np.int64)[:, None, None]
+    x = np.arange(width, dtype=np.int64)[None, :, None]
+    ch = np.arange(3, dtype=np.int64)[None, None, :]
+    base = (x * (2 + ch) // 3 + y * (1 + ch) + 40 * np.sin((x + 3 * y) / 97.0).astype(np.int64))
+    noise = rng.integers(0, 3, size=(rows, width, 3))
+    img = ((base + noise) & 255).astype(np.uint8).reshape(rows, width * 3)
+    sub = img.copy()
+    sub[:, 3:] = img[:, 3:] - img[:, :-3]          # PNG filter type 1 (Sub), bpp = 3
+    out = np.empty((rows, row), dtype=np.uint8)
+    out[:, 0] = 1
+    out[:, 1:] = sub
+    return out.tobytes()[:n]
+
+
+def mixed_spec(i, seed=5):
+    """Stream i of the config-5 mix (PNG-IDAT-like streams of 1-16 MiB and 1 MiB text members, interleaved by a seeded
+    choice) without generating it: -> (kind, uncompressed length)."""
+    rng = random.Random((seed << 20) ^ i)
+    if rng.random() < 0.25:
+        return "idat", rng.randint(1, 16) << 20
+    return "gzip", 1 << 20
+
+
+def mixed_stream(i, seed=5):
+    """-> (kind, raw bytes, zlib-9 raw deflate stream) of stream i of the config-5 mix."""
+    kind, n = mixed_spec(i, seed)
+    raw = pngidat(n, 0x1DA7 + i) if kind == "idat" else reptext(n, 0xD4F7 + i)
+    return kind, raw, deflate9(raw)

@@ -50,3 +50,19 @@ def test_product_library_does_not_link_the_oracle():
     assert "oracle" not in src.lower() or "deft_oracle" not in src
     py = open(os.path.join(ROOT, "deft4j_amd", "__init__.py")).read() + open(os.path.join(ROOT, "deft4j_amd", "shard.py")).read()
     assert "oracle" not in py
+
+
+def test_jni_shim_and_java_binding_match_the_header():
+    """jni/deft4g_jni.c and java/.../NativeDeft.java cannot be compiled here (no JDK), so keep them honest textually:
+    every d4g_ function the shim calls is declared in include/deft4g.h, and every native method of NativeDeft has its
+    Java_..._NativeDeft_<name> definition in the shim."""
+    hdr = open(os.path.join(ROOT, "include", "deft4g.h")).read()
+    shim = open(os.path.join(ROOT, "jni", "deft4g_jni.c")).read()
+    java = open(os.path.join(ROOT, "java", "com", "github", "NeRdTheNed", "deft4j", "NativeDeft.java")).read()
+    declared = set(re.findall(r"\b(d4g_[a-z_0-9]+)\s*\(", hdr))
+    for f in set(re.findall(r"\b(d4g_[a-z_0-9]+)\s*\(", shim)):
+        assert f in declared, f
+    natives = re.findall(r"native\s+[\w\[\]]+\s+(\w+)\s*\(", java)
+    assert len(natives) >= 6
+    for m in natives:
+        assert "JFN(%s)" % m in shim, m

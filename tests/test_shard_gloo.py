@@ -21,13 +21,19 @@ dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=ran
 L = D.load_library(os.path.join(%(root)r, 'tests', 'hostsim', 'libdeft4g_hostsim.so'))
 D.init(0, lib=L)
 streams = [synth.make_stream(n, s) for n, s in ((900, 1), (2500, 2), (300, 3), (1800, 4), (1200, 5))] + [b'\x07']
-res = shard.optimise_sharded(streams, False, lambda ss: D.Batch(ss, lib=L), dist=dist)
+loaded = []
+def load(i):
+    loaded.append(i)
+    return streams[i]
+res = shard.optimise_sharded([len(s) for s in streams], load, False, lambda ss: D.Batch(ss, lib=L), dist=dist, batch_bytes=600)
+mine = shard.lpt_partition([len(s) for s in streams], world)[rank]
+assert sorted(loaded) == mine, (loaded, mine)          # a rank only materialises its own shard
 if rank == 0:
     total, outs, saved = res
     want = [O.optimise(s, False) for s in streams]
-    assert total == sum(max(w[2], 0) for w in want), (total, saved)
+    assert total == sum(w[2] for w in want if w[0] == 0), (total, saved)
     for s, o, w in zip(streams, outs, want):
-        assert o == (w[1] if w[0] >= 0 else s)
+        assert o == (w[1] if w[0] == 0 else None)       # unchanged / malformed: None, the caller keeps its original
     print('SHARD_OK', total)
 else:
     assert res is None
