@@ -740,7 +740,7 @@ struct Batch {
             b.binMask = binMaskWords;
             if (needSlots) binMaskWords += (i64)D4G_NBINS * maskWordsCap;
             b.passMemo = needSlots ? passMemoWords : -1;
-            b.passMemoStride = D4G_PASSMEMO_HDR_WORDS + maskWordsCap;
+            b.passMemoStride = D4G_PASSMEMO_HDR_WORDS + 2 * maskWordsCap;   // header + key codes, outgoing mask, incoming mask (key)
             if (needSlots) passMemoWords += (i64)D4G_PASSMEMO_SLOTS * b.passMemoStride;
             maskWordsTotal += maskWordsCap * masksAlloc;
             hBlocks.push_back(b);
@@ -891,15 +891,24 @@ struct Batch {
             rt_memset(dChanged, 0, 40 * 8);
             i64 totalU = 0;
             for (size_t i = 0; i < n; i++) totalU += ps[i].nU;
-            for (int round = 0; round < 40; round++) {
-                RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged + round, G);
-                stats.kernel_launches++;
-                unsigned long long ch = 0;
-                rt_d2h(&ch, dChanged + round, 8);
-                stats.jump_rounds++;
-                static int stopPct = -1;   // D4G_JUMP_STOP_PCT: stop doubling once fewer than this share of the bytes still moves
-                if (stopPct < 0) { const char* t = getenv("D4G_JUMP_STOP_PCT"); stopPct = t ? atoi(t) : 50; }
-                if ((i64)ch * 100 < totalU * stopPct) break;   // the resolve pass walks what is left of the chains
+            static int stopPct = -1;   // D4G_JUMP_STOP_PCT: stop doubling once fewer than this share of the bytes still moves
+            if (stopPct < 0) { const char* t = getenv("D4G_JUMP_STOP_PCT"); stopPct = t ? atoi(t) : 50; }
+            const unsigned long long stopNum = std::max<unsigned long long>(1, (unsigned long long)((totalU * stopPct + 99) / 100));   // the resolve pass walks what is left of the chains
+            const int JB = 10;   // rounds per batch: launched back to back, counters read once
+            for (int base = 0; base < 40; base += JB) {
+                for (int round = base; round < base + JB; round++) {
+                    RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged + round, G,
+                              round == 0 ? (const unsigned long long*)nullptr : dChanged + round - 1, stopNum);
+                    stats.kernel_launches++;
+                }
+                unsigned long long ch[JB];
+                rt_d2h(ch, dChanged + base, JB * 8);
+                bool done = false;
+                for (int k = 0; k < JB; k++) {
+                    stats.jump_rounds++;                   // round base + k ran (its predecessor moved enough)
+                    if (ch[k] < stopNum) { done = true; break; }
+                }
+                if (done) break;
             }
             RT_LAUNCH(k_resolve_streams, n * (size_t)G, 256, dStreams, dSrc, dU, G);
             stats.kernel_launches++;
@@ -1283,11 +1292,30 @@ struct Batch {
         d.passMemo = -1;
         hBlocks[home] = d;
         gpuType[home] = gpuType[hb.gpu];
-        rt_h2d(dBlocks + home, &hBlocks[home], sizeof(D4GBlock));
+        patch_block(home);
         pendingCommits.push_back({hb.gpu, 0, home, 0});
         hb.gpu = home;
     }
+    // descriptor changes are collected and applied by one upload + one scatter kernel (k_patch_blocks)
+    std::map<int32_t, D4GBlock> blockPatches;
+    void patch_block(int idx) { blockPatches[idx] = hBlocks[idx]; }
+    void flush_block_patches() {
+        if (blockPatches.empty()) return;
+        std::vector<int32_t> idx;
+        std::vector<D4GBlock> src;
+        for (auto& kv : blockPatches) { idx.push_back(kv.first); src.push_back(kv.second); }
+        blockPatches.clear();
+        int32_t* dIdx = (int32_t*)rt_malloc(idx.size() * 4);
+        D4GBlock* dSrcB = (D4GBlock*)rt_malloc(src.size() * sizeof(D4GBlock));
+        rt_h2d(dIdx, idx.data(), idx.size() * 4);
+        rt_h2d(dSrcB, src.data(), src.size() * sizeof(D4GBlock));
+        RT_LAUNCH(k_patch_blocks, idx.size(), 64, dBlocks, dIdx, dSrcB, (int)idx.size());
+        stats.kernel_launches++;
+        rt_sync();   // (the staging buffers go back to the pool)
+        rt_free(dIdx); rt_free(dSrcB);
+    }
     void flush_commits(D4GMergeJob* dJobs) {
+        flush_block_patches();
         if (pendingCommits.empty()) return;
         rt_h2d(dJobs, pendingCommits.data(), pendingCommits.size() * sizeof(D4GMergeJob));
         D4GCtx c = make_ctx(engine().progFixed, 0);
@@ -1314,7 +1342,7 @@ struct Batch {
                     j.blkM = rq.arena;
                     j.pad = 0;
                     jobs.push_back(j);
-                    rt_h2d(dBlocks + rq.arena, &hBlocks[rq.arena], sizeof(D4GBlock));
+                    patch_block(rq.arena);
                 }
             }
             flush_commits(dJobs);   // before any arena is overwritten
@@ -1329,6 +1357,7 @@ struct Batch {
             for (size_t i = 0; i < reqs.size(); i++) merge_apply(reqs[i].stream, reqs[i].arena, res[i]);
         }
         rt_free(dJobs);
+        flush_block_patches();
         check_device_errors();
         for (HStream& s : streams)
             if (s.status == 0) s.saved += s.mSaved;

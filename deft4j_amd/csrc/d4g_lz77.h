@@ -37,7 +37,7 @@
 #define LZ_WARM 512            // a speculative chunk starts this many positions early
 #define LZ_MAX_DIST 32506      // w_size - MIN_LOOKAHEAD
 #define LZ_SYMS_PER_BLOCK 16383
-#define LZ_WIN_SLACK 288       // bytes staged past the last chunk (MAX_MATCH + word reads)
+#define LZ_WIN_SLACK 304       // bytes staged past the last chunk (MAX_MATCH + the 8-byte compare's over-read)
 
 #define LZ_DEFAULT 0
 #define LZ_FILTERED 1
@@ -195,6 +195,12 @@ D4G_DEV uint32_t lz_load4(const uint32_t* win, int off) {   // bytes [off, off+4
     return (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh);
 }
 
+D4G_DEV unsigned long long lz_load8(const uint32_t* win, int off) {   // bytes [off, off+8)
+    const int i = off >> 2, sh = (off & 3) * 8;
+    const unsigned long long lo = ((unsigned long long)win[i + 1] << 32) | win[i];
+    return sh ? (lo >> sh) | ((unsigned long long)win[i + 2] << (64 - sh)) : lo;
+}
+
 D4G_DEV void lz_search(const LzCtx& c, const LzStream& st, const uint32_t* win, long long w0, long long p, int bestInit, int maxChain,
                        int& bestLen, int& bestDist) {
     const int lane = threadIdx.x & 63;
@@ -238,10 +244,10 @@ D4G_DEV void lz_search(const LzCtx& c, const LzStream& st, const uint32_t* win, 
             const unsigned msk = best >= 3 ? 0xffffffffu : 0x00ffffffu;
             if (((lz_load4(win, co + off) ^ lz_load4(win, po + off)) & msk) == 0) {
                 int k = 0;
-                while (k < maxcmp) {
-                    unsigned x = lz_load4(win, co + k) ^ lz_load4(win, po + k);
-                    if (x) { k += (__ffs((int)x) - 1) >> 3; break; }
-                    k += 4;
+                while (k < maxcmp) {   // eight bytes per step
+                    unsigned long long x = lz_load8(win, co + k) ^ lz_load8(win, po + k);
+                    if (x) { k += (__ffsll((long long)x) - 1) >> 3; break; }
+                    k += 8;
                 }
                 len = k < maxcmp ? k : maxcmp;
             }
@@ -264,7 +270,7 @@ D4G_DEV void lz_search(const LzCtx& c, const LzStream& st, const uint32_t* win, 
 // exact = 0: every chunk but a stream's first starts LZ_WARM positions early from a clean state and records from its
 //            first loop top inside the chunk;  exact = 1: the chunk starts from its predecessor's recorded exit state.
 // ---------------------------------------------------------------------------------------------------------------------
-#define LZ_PARSE_MAXWAVES 4
+#define LZ_PARSE_MAXWAVES 16   // 16 chunks share one staged window: 66 KB of LDS, two workgroups = 32 waves per CU
 __global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, const LzParseJob* jobs, int exact) {
     __shared__ uint32_t win[(32768 + LZ_WARM + LZ_PARSE_MAXWAVES * LZ_CHUNK + LZ_WIN_SLACK + 64) / 4];
     const LzParseJob job = jobs[blockIdx.x];
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, co
     w0 &= ~15LL;
     long long w1 = tile0 + (long long)nw * LZ_CHUNK + LZ_WIN_SLACK;
     {   // stage [w0, w1): the input is padded with zero bytes, so reading past st.len is harmless
-        long long lim = ((st.len + 15) & ~15LL) + 304;
+        long long lim = ((st.len + 15) & ~15LL) + 320;
         if (w1 > lim) w1 = lim;
         const int nvec = (int)((w1 - w0 + 15) >> 4);
         const uint4* src = (const uint4*)(st.data + w0);

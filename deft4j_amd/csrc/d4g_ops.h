@@ -65,7 +65,9 @@ struct D4GHsMemo {
     int32_t state;              // 0 free/claimed, 2 published
     int32_t hdr;                // header bits of the best candidate
     int32_t lane;               // which candidate
-    int32_t pad;
+    int32_t nLit;               // the key: nLit, n and the n combined code lengths (zero padded) — hits are confirmed against it
+    int32_t n, pad;
+    uint32_t key[(D4G_NLIT + D4G_NDIST) / 4];
 };
 
 // Huffman-rebuild memo.  recodeHuffman's result (both codes, the default header's RLE pairs and code-length code,
@@ -81,6 +83,7 @@ struct D4GRecodeMemo {
     int32_t state, nLit, nDist, nCl, nPairs, err;
     long long litlenBits, hdrBits;
     uint32_t body[D4G_RCMEMO_WORDS];
+    uint32_t key[D4G_HIST];     // the histogram the entry was built from: hits are confirmed against it
 };
 static_assert(offsetof(D4GState, litLen) == 64 && offsetof(D4GState, hist) == 64 + 4 * D4G_RCMEMO_WORDS, "memo body covers lengths + pairs");
 
@@ -96,7 +99,9 @@ struct D4GPassMemo {
     int32_t state, pad;
     long long saved;
     int32_t delta[D4G_HIST];
-    // followed by maskWords u64
+    uint32_t keyCodes[(D4G_NLIT + D4G_NDIST) / 4];   // the key: both codes, the comparison mode ...
+    int32_t keyKind, pad2;
+    // followed by maskWords u64 (the outgoing mask) and maskWords u64 (the incoming mask: the rest of the key)
 };
 #define D4G_PASSMEMO_HDR_WORDS ((int)(sizeof(D4GPassMemo) / 8))
 
@@ -334,9 +339,22 @@ __device__ __forceinline__ int wg_passmemo_lookup(D4GLds* L, const D4GCtx& c, co
         L->misc[63] = (int)idx;
     }
     __syncthreads();
-    const int role = L->misc[62];
+    int role = L->misc[62];
     entry = (D4GPassMemo*)(pool + (long long)L->misc[63] * b.passMemoStride);
     __syncthreads();
+    // The hashes only find the entry; what decides is the key itself: codes, comparison mode and incoming mask.
+    uint64_t* keyMask = (uint64_t*)entry + D4G_PASSMEMO_HDR_WORDS + b.maskWords;
+    if (role == 1) {   // ours: the key goes in now, the result and the flag follow when the pass is done
+        for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) st_sc1(&entry->keyCodes[i], lw[i]);
+        for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) st_sc1(keyMask + w, ld_sc1(maskIn + w));
+        if (threadIdx.x == 0) st_sc1((uint32_t*)&entry->keyKind, (uint32_t)kind);
+    } else if (role == 2) {
+        int bad = 0;
+        for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) bad |= ld_sc1(&entry->keyCodes[i]) != lw[i];
+        for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) bad |= ld_sc1(keyMask + w) != ld_sc1(maskIn + w);
+        if (threadIdx.x == 0) bad |= ld_state_i32(&entry->keyKind) != kind;
+        if (wg_max_i32(bad, L->red)) { role = 0; entry = nullptr; }   // same hashes, different key: compute without the memo
+    }
     return role;
 }
 // a published entry applied to the state in LDS: outgoing mask, histogram deltas, bits saved
@@ -1044,9 +1062,17 @@ __device__ __forceinline__ void wg_recode_huffman(D4GLds* L, D4GRecodeMemo* memo
             L->misc[63] = (int)idx;
         }
         __syncthreads();
-        const int role = L->misc[62];
+        int role = L->misc[62];
         D4GRecodeMemo* e = memoTab + L->misc[63];
         __syncthreads();
+        // the hashes only find the entry: a hit is confirmed against the histogram it was built from
+        if (role == 1) {
+            for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) st_sc1(&e->key[i], S->hist[i]);
+        } else if (role == 2) {
+            int bad = 0;
+            for (int i = threadIdx.x; i < D4G_HIST; i += blockDim.x) bad |= ld_sc1(&e->key[i]) != S->hist[i];
+            if (wg_max_i32(bad, L->red)) role = 0;
+        }
         if (role == 2) {
             for (int i = threadIdx.x; i < D4G_RCMEMO_WORDS; i += blockDim.x) ((uint32_t*)S)[16 + i] = ld_sc1(&e->body[i]);
             if (threadIdx.x == 0) {
@@ -1611,7 +1637,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
     // code lengths word by word (litLen and distLen are 4-byte aligned, contiguous in the state)
     for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) ((uint32_t*)H.lens)[i] = ld_sc1((const uint32_t*)base->litLen + i);
     __syncthreads();
-    for (int i = lane; i < n; i += 64) comb[i] = i < nLit ? H.lens[i] : H.lens[D4G_NLIT + i - nLit];
+    for (int i = lane; i < D4G_NLIT + D4G_NDIST; i += 64) comb[i] = i >= n ? 0 : i < nLit ? H.lens[i] : H.lens[D4G_NLIT + i - nLit];
     __syncthreads();
     long long baseLitlenBits = (long long)ld_sc1((const uint64_t*)&base->litlenBits);
     // ---- memo lookup: two position-keyed 64-bit hashes of the length set ----
@@ -1632,11 +1658,12 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
         if (h1 == 0) h1 = 1;
         D4GHsMemo* tab = c.hsMemo + (long long)blk * D4G_HSMEMO_SLOTS;
         long long found = -1;   // >= 0: published result (hdr << 8 | lane)
+        int slot = -1;          // the entry claimed (mine) or hit
         if (lane == 0) {
             for (int probe = 0; probe < 8; probe++) {
                 D4GHsMemo* e = tab + ((h1 >> 7) + probe) % D4G_HSMEMO_SLOTS;
                 unsigned long long t = atomicCAS(&e->tag, 0ULL, h1);
-                if (t == 0) { mine = e; break; }           // ours to compute
+                if (t == 0) { mine = e; slot = (int)(e - tab); break; }           // ours to compute
                 if (t == h1) {                             // someone has it or is computing it: wait for the result
                     int st = 0;
                     for (int spin = 0; spin < (1 << 18); spin++) {
@@ -1644,13 +1671,32 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
                         if (st == 2) break;
                         d4g_sleep();
                     }
-                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2)
+                    if (st == 2 && ld_sc1((const uint64_t*)&e->check) == (uint64_t)h2) {
                         found = ((long long)ld_state_i32(&e->hdr) << 8) | (long long)ld_state_i32(&e->lane);
+                        slot = (int)(e - tab);
+                    }
                     break;                                 // (timeout or a hash clash: compute without the memo)
                 }
             }
         }
         found = __shfl(found, 0);
+        slot = __shfl(slot, 0);
+        const bool owner = __shfl(mine != nullptr ? 1 : 0, 0) != 0;
+        // the hashes only find the entry: the key (nLit, n, the code lengths) is written by the owner at claim time and
+        // a hit is confirmed against it.  comb[] is zero beyond n (cleared above), so whole words compare.
+        if (slot >= 0) {
+            D4GHsMemo* e = tab + slot;
+            const uint32_t* cw = (const uint32_t*)comb;
+            if (owner) {
+                for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) st_sc1(&e->key[i], cw[i]);
+                if (lane == 0) { st_sc1((uint32_t*)&e->nLit, (uint32_t)nLit); st_sc1((uint32_t*)&e->n, (uint32_t)n); }
+            } else if (found >= 0) {
+                bool bad = false;
+                for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) bad |= ld_sc1(&e->key[i]) != cw[i];
+                if (lane == 0) bad |= ld_state_i32(&e->nLit) != nLit || ld_state_i32(&e->n) != n;
+                if (__ballot(bad)) found = -1;             // same hashes, different lengths: compute without the memo
+            }
+        }
         if (found >= 0) {
             if (lane == 0) *keyp = D4G_MAKE_KEY(baseLitlenBits + (found >> 8), (long long)opId * 64 + (found & 255));
             return;
@@ -1735,7 +1781,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
 
 __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {
     __shared__ D4GHdrLds H;
-    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
+    __shared__ __attribute__((aligned(16))) uint8_t comb[D4G_NLIT + D4G_NDIST];   // (compared word-wise against the memo's key)
     int bs, orel;
     if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
     d4g_exec_hdr_search(H, comb, c, c.active[bs], opList[orel]);
@@ -1743,7 +1789,7 @@ __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t*
 
 __global__ void __launch_bounds__(64) k_persist_hdr_search(D4GCtx c, D4GQueue q) {
     __shared__ D4GHdrLds H;
-    __shared__ uint8_t comb[D4G_NLIT + D4G_NDIST];
+    __shared__ __attribute__((aligned(16))) uint8_t comb[D4G_NLIT + D4G_NDIST];   // (compared word-wise against the memo's key)
     __shared__ int sTask[3], sOk;
     int cursor = 0;
     while (true) {

@@ -822,7 +822,12 @@ __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, 
 }
 
 // One stream per blockIdx.y.  In place: reading a concurrently updated entry still yields an ancestor.
-__global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* streams, uint32_t* src, unsigned long long* changed, int G) {
+// `prev` (the previous round's moved-entries counter, nullptr for the first round): the rounds of a batch are launched
+// back to back and a round whose predecessor moved fewer than stopNum entries does nothing — the host reads the counters
+// once per batch instead of once per round.
+__global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* streams, uint32_t* src, unsigned long long* changed, int G,
+                                                      const unsigned long long* prev, unsigned long long stopNum) {
+    if (prev && *prev < stopNum) return;
     const D4GStreamDesc sd = streams[blockIdx.x / G];
     uint32_t* s = src + sd.uBase;   // uBase is a multiple of 16: four entries per 16-byte load
     const long long n4 = sd.uLen >> 2;

@@ -9,6 +9,14 @@
 #pragma once
 #include "d4g_ops.h"
 
+// LDS writes of a wave's lanes must be visible to its other lanes before they are read back (the LDS executes one wave's
+// operations in order; the barrier keeps the compiler from moving them across)
+#ifdef D4G_HOSTSIM
+#define D4G_WAVE_LDS_SYNC() ((void)__ballot(1))
+#else
+#define D4G_WAVE_LDS_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 struct D4GWriteJob {
     int32_t blk;        // block index (Huffman: its slot 0 is written; stored: only the data range is used)
     int32_t type;       // final type to write
@@ -55,6 +63,18 @@ __device__ void t0_canonical_codes(const uint8_t* lens, int n, uint16_t* codes) 
     }
 }
 
+// Output words a wave assembles in LDS per step of 64 tokens before it touches memory: interior words are written with one
+// plain store each, only the two words it may share with its neighbours go through atomicOr.  64 tokens x 48 bits fit;
+// a step that holds more (several long back-references expanded to literals) falls back to per-token atomics.
+#define D4G_STAGE_WORDS 128
+D4G_DEV void stage_bits(uint32_t* st, int relBit, uint64_t bits, int n) {   // relBit counted from the first staged word's bit 0
+    if (n <= 0) return;
+    int w = relBit >> 5, sh = relBit & 31;
+    atomicOr(&st[w], (uint32_t)(bits << sh));
+    if (sh + n > 32) atomicOr(&st[w + 1], (uint32_t)(bits >> (32 - sh)));
+    if (sh + n > 64) atomicOr(&st[w + 2], (uint32_t)(bits >> (64 - sh)));
+}
+
 struct D4GWriteLds {
     D4GState st;
     uint16_t litCode[D4G_NLIT];
@@ -62,6 +82,7 @@ struct D4GWriteLds {
     uint16_t clCode[20];
     long long scan[16];
     long long base;
+    uint32_t stage[16][D4G_STAGE_WORDS + 2];   // per wave: the output words of its current 64 tokens
 };
 
 __global__ void __launch_bounds__(1024) k_write(D4GCtx c, const D4GWriteJob* jobs, uint32_t* out) {
@@ -74,10 +95,15 @@ __global__ void __launch_bounds__(1024) k_write(D4GCtx c, const D4GWriteJob* job
             unsigned len = (unsigned)job.uLen;
             put_bits(out, dataByte * 8, (uint64_t)(len & 0xffff) | ((uint64_t)((~len) & 0xffff) << 16), 32);
         }
+        // the payload: whole output words get one plain store, the (up to two) partial ones an atomicOr
         const uint8_t* src = c.U + job.uAbs;
-        for (long long i = threadIdx.x; i < job.uLen; i += blockDim.x) {
-            long long ob = dataByte + 4 + i;
-            atomicOr(&out[ob >> 2], (uint32_t)src[i] << (8 * (ob & 3)));
+        const long long o0 = dataByte + 4, o1 = o0 + job.uLen;
+        for (long long w = (o0 >> 2) + threadIdx.x; w <= ((o1 - 1) >> 2) && job.uLen > 0; w += blockDim.x) {
+            long long lo = w * 4 < o0 ? o0 : w * 4, hi = w * 4 + 4 > o1 ? o1 : w * 4 + 4;
+            uint32_t v = 0;
+            for (long long q = lo; q < hi; q++) v |= (uint32_t)src[q - o0] << (8 * (q & 3));
+            if (hi - lo == 4) out[w] = v;
+            else atomicOr(&out[w], v);
         }
         return;
     }
@@ -160,30 +186,57 @@ __global__ void __launch_bounds__(1024) k_write(D4GCtx c, const D4GWriteJob* job
         long long waveBase = 0, total = 0;
         for (int i = 0; i < nw; i++) { if (i < wave) waveBase += W.scan[i]; total += W.scan[i]; }
         long long pos = W.base + waveBase + incl - nbits;
+        // this wave's 64 tokens cover bits [wStart, wStart + wBits): assemble them in LDS, then store whole words
+        const long long wStart = W.base + waveBase;
+        const long long wBits = __shfl(incl, 63);
+        const long long word0 = wStart >> 5;
+        const int nWords = wBits > 0 ? (int)(((wStart + wBits - 1) >> 5) - word0 + 1) : 0;
+        const bool staged = nWords <= D4G_STAGE_WORDS;
+        uint32_t* stg = W.stage[wave];
+        if (staged) for (int k = lane; k < nWords + 2; k += 64) stg[k] = 0;
+        D4G_WAVE_LDS_SYNC();
+        const int rel = (int)(pos - (word0 << 5));
+        uint64_t bits = 0;
+        int n = 0;
         if (kind == 1) {
             int val = tok_val(a);
-            put_bits(out, pos, W.litCode[val], S->litLen[val]);
+            bits = W.litCode[val];
+            n = S->litLen[val];
         } else if (kind == 2) {
             int len = tok_val(a), dist = tok_dist(a);
             int ls = d4g_len2sym(len, tok_edge(a)), ds = d4g_dist2sym(dist);
-            uint64_t bits = W.litCode[ls];
-            int n = S->litLen[ls];
+            bits = W.litCode[ls];
+            n = S->litLen[ls];
             bits |= (uint64_t)(len - d4g_lsym_base(ls)) << n;
             n += d4g_lsym_ebits(ls);
             bits |= (uint64_t)W.distCode[ds] << n;
             n += S->distLen[ds];
             bits |= (uint64_t)(dist - d4g_dsym_base(ds)) << n;
             n += d4g_dsym_ebits(ds);
-            put_bits(out, pos, bits, n);
+        }
+        if (kind == 1 || kind == 2) {
+            if (staged) stage_bits(stg, rel, bits, n);
+            else put_bits(out, pos, bits, n);
         } else if (kind == 3) {
             int len = tok_val(a);
             const uint8_t* p = Ub + toff;
+            long long pp = pos;
             for_bytes(p, len, [&](int by) {
                 int l = S->litLen[by];
-                put_bits(out, pos, W.litCode[by], l);
-                pos += l;
+                if (staged) stage_bits(stg, (int)(pp - (word0 << 5)), W.litCode[by], l);
+                else put_bits(out, pp, W.litCode[by], l);
+                pp += l;
                 return true;
             });
+        }
+        D4G_WAVE_LDS_SYNC();
+        if (staged) {
+            const bool headShared = (wStart & 31) != 0, tailShared = ((wStart + wBits) & 31) != 0;
+            for (int k = lane; k < nWords; k += 64) {
+                uint32_t v = stg[k];
+                if ((k == 0 && headShared) || (k == nWords - 1 && tailShared)) { if (v) atomicOr(&out[word0 + k], v); }
+                else out[word0 + k] = v;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) W.base += total;
@@ -277,6 +330,15 @@ __global__ void __launch_bounds__(256) k_make_merged(D4GCtx c, const D4GMergeJob
 
 // A finished merged block leaves its arena: state slot 0 and the current mask of `blkA` are copied to slot 0 / mask 0
 // of `blkM` (whose descriptor the host has already rewritten to the merged token range).
+// block descriptors the host changed (merge arenas, committed merged blocks): one upload + one scatter per round instead
+// of one small copy per descriptor
+__global__ void __launch_bounds__(64) k_patch_blocks(D4GBlock* blocks, const int32_t* idx, const D4GBlock* src, int n) {
+    if ((int)blockIdx.x >= n) return;
+    const uint32_t* s = (const uint32_t*)(src + blockIdx.x);
+    uint32_t* d = (uint32_t*)(blocks + idx[blockIdx.x]);
+    for (int i = threadIdx.x; i < (int)(sizeof(D4GBlock) / 4); i += blockDim.x) d[i] = s[i];
+}
+
 __global__ void __launch_bounds__(256) k_commit_merged(D4GCtx c, const D4GMergeJob* jobs) {
     const D4GMergeJob job = jobs[blockIdx.x];
     const D4GBlock bA = c.blocks[job.blkA], bM = c.blocks[job.blkM];
