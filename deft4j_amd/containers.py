@@ -365,8 +365,10 @@ def detect(data):
     return None
 
 
-def optimise_files(files, merge_blocks=True, formats=None, lib=None):
+def optimise_files(files, merge_blocks=True, formats=None, lib=None, mode=0):
     """files: list of bytes.  formats: optional list of container instances / None (auto-detect) / "raw".
+    mode: RecompressMode ordinal of `deft4j optimise --mode` (0 NONE, 1 CHEAP; M/CMDUtil.java:44-50,76-105): above NONE every
+    stream is also recompressed and the recompression grafted in where it is smaller.
     Returns [(output bytes or None when unreadable, transcript lines)] — the lines M/CMDUtil.java:64-74 and
     K/DeflateFilesContainer.java:31-40 print.  Every deflate stream of every file goes to the GPU in one batch."""
     conts = []
@@ -386,7 +388,10 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
         for name, pl in sp:
             payloads.append(pl)
             owner.append((i, name))
-    batch = Batch(payloads, lib=lib).run(merge_blocks) if payloads else None
+    batch = None
+    if payloads:
+        batch = Batch(payloads, lib=lib)
+        batch.run_recompress(mode, merge_blocks) if mode > 0 else batch.run(merge_blocks)
     results = [(None, ["Failed to read file"]) for _ in files]
     k = 0
     for i, c in enumerate(conts):
@@ -397,6 +402,7 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
         total = 0
         ok = True
         pieces = []
+        rlines, rtotal = [], 0
         for j in range(n):
             r = batch.result(k + j)
             if r["status"] < 0:
@@ -406,11 +412,20 @@ def optimise_files(files, merge_blocks=True, formats=None, lib=None):
             if saved > 0:
                 lines.append("%d bits saved in stream %d (%s)" % (saved, j, owner[k + j][1]))
             total += saved
+            if mode > 0:
+                grafted, rs = batch.recompress_result(k + j)
+                if grafted:                      # M/CMDUtil.java:94-98
+                    orig = r["size_bits_in"] - saved
+                    rlines.append("Recompressed stream %d (%s) from %d bits to %d bits, saved %d bits" % (j, owner[k + j][1], orig, orig - rs, rs))
+                    rtotal += rs
             pieces.append((batch.output(k + j), None if isinstance(c, ZipFile) else batch.checksums(k + j)))
         if ok:
             if total > 0:
                 lines.append("Total bits saved %d" % total)
                 lines.append("Saved %d bits with optimisation" % total)
+            lines += rlines
+            if rtotal > 0:
+                lines.append("Saved %d bits with recompression" % rtotal)
             if isinstance(c, ZipFile):   # members keep their CRC-32 (the decoded bytes do not change)
                 results[i] = (c.write([pc[0] for pc in pieces]), lines)
             elif isinstance(c, PNGFile):

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -51,13 +52,12 @@ static inline int wide_block() {
     return v;
 }
 static inline int lanes() {
-    static int v = 0;
-    if (!v) {
-        const char* t = getenv("D4G_LANES");  // tuning knob: block groups running their level sequences concurrently
-        v = t ? atoi(t) : 2;  // measured on MI355X: 1 -> 587, 2 -> 627, 4 -> 494, 8 -> 349 MB/s on config 2
-        if (v < 1) v = 1;
-        if (v > RT_MAX_LANES) v = RT_MAX_LANES;
-    }
+    // tuning knob, read per call: block groups running their level sequences concurrently.  bench.py's roofline leg
+    // sets it to 1 so that a launch's event-timed duration is not inflated by the neighbouring lane.
+    const char* t = getenv("D4G_LANES");
+    int v = t ? atoi(t) : 2;  // measured on MI355X: 1 -> 587, 2 -> 627, 4 -> 494, 8 -> 349 MB/s on config 2
+    if (v < 1) v = 1;
+    if (v > RT_MAX_LANES) v = RT_MAX_LANES;
     return v;
 }
 
@@ -381,7 +381,6 @@ static void build_hdr_tables(uint8_t* flags, uint8_t* prune) {
 struct Engine {  // per-process device objects shared by all batches
     Program progDyn, progFixed;
     uint8_t* dHdrTables = nullptr;  // flags[64] + prune[64]
-    int32_t* dErrors = nullptr;
     long long* dOpStats = nullptr;
     uint32_t* dCrcTab = nullptr;   // [1024] slice-by-4 CRC-32 tables, then [32] x^(2^k) mod P
     int slotsPerBlock = 0, masksPerBlock = 0, maxOps = 0;
@@ -390,11 +389,13 @@ struct Engine {  // per-process device objects shared by all batches
     void release() {
         if (!ready) return;
         progDyn.release(); progFixed.release();
-        rt_free(dHdrTables); rt_free(dErrors); rt_free(dOpStats); rt_free(dCrcTab);
-        dHdrTables = nullptr; dErrors = nullptr; dOpStats = nullptr; dCrcTab = nullptr;
+        rt_free(dHdrTables); rt_free(dOpStats); rt_free(dCrcTab);
+        dHdrTables = nullptr; dOpStats = nullptr; dCrcTab = nullptr;
         ready = false;
     }
     void init() {
+        static std::mutex initMu;   // several host threads may arrive with the first batches
+        std::lock_guard<std::mutex> lk(initMu);
         if (ready) return;
         if (!built) {
             progDyn.build(false);
@@ -405,6 +406,14 @@ struct Engine {  // per-process device objects shared by all batches
             fprintf(stderr, "program: %d ops requested, %zu emitted (%zu header searches over %zu distinct code-length sets), %d levels, %d slots, %d masks\n",
                     progDyn.nRequested, progDyn.ops.size(), (size_t)std::count_if(progDyn.ops.begin(), progDyn.ops.end(), [](const D4GOp& o) { return o.kind == OP_HDRSEARCH; }),
                     progDyn.hsCodes.size(), progDyn.nLevels, progDyn.nSlots, progDyn.nMasks);
+        if (const char* dp = getenv("D4G_DEBUG_PROGRAM"))
+            if (atoi(dp) >= 2)
+                for (int l = 0; l < progDyn.nLevels; l++) {
+                    int kinds[16] = {0};
+                    for (int id : progDyn.stateLevels[l]) kinds[progDyn.ops[id].kind * 1 + 0]++;
+                    fprintf(stderr, "level %2d: OPT %d RECODE %d FULL %d LEAST %d POST %d PRUNEHDR %d TOFIXED %d CAND %d | hdr searches %zu\n", l, kinds[1], kinds[2],
+                            kinds[3], kinds[4], kinds[5], kinds[6], kinds[7], kinds[8], progDyn.hdrLevels[l].size());
+                }
         progDyn.upload();
         progFixed.upload();
         uint8_t tab[128];
@@ -412,8 +421,6 @@ struct Engine {  // per-process device objects shared by all batches
         build_hdr_tables(tab, tab + 64);
         dHdrTables = (uint8_t*)rt_malloc(128);
         rt_h2d(dHdrTables, tab, 128);
-        dErrors = (int32_t*)rt_malloc(4);
-        rt_memset(dErrors, 0, 4);
         dOpStats = (long long*)rt_malloc(64 * 8);
         rt_memset(dOpStats, 0, 64 * 8);
         {
@@ -506,6 +513,7 @@ struct Batch {
     D4GState* dStates = nullptr;
     uint64_t* dMasks = nullptr;
     long long* dKeys = nullptr;
+    int32_t* dErr = nullptr;       // device consistency counter of THIS batch (kernels add to it; checked after each phase)
     int32_t* dActive = nullptr;
     D4GRoundResult* dResults = nullptr;
     uint32_t* dOut = nullptr;
@@ -520,9 +528,14 @@ struct Batch {
     ~Batch() {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
         rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dPassMemo); rt_free(chunkPool.batches); rt_free(chunkPool.next); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
+        rt_free(dErr);
         rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
     }
 
+    int32_t* errors() {
+        if (!dErr) { dErr = (int32_t*)rt_malloc(16); rt_memset(dErr, 0, 16); }
+        return dErr;
+    }
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
@@ -531,7 +544,7 @@ struct Batch {
             if (m[0] == '0') { c.hsMemo = nullptr; c.rcMemo = nullptr; c.passMemo = nullptr; }
         } c.U = dU; c.blocks = dBlocks; c.states = dStates; c.masks = dMasks;
         c.keys = dKeys; c.ops = P.dOps; c.hdrFlags = E.dHdrTables; c.hdrPrune = E.dHdrTables + 64;
-        c.active = dActive; c.errors = E.dErrors; c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
+        c.active = dActive; c.errors = errors(); c.opStats = E.dOpStats; c.nActive = nActive; c.nOps = (int)P.ops.size();
         c.slotsPerBlock = slotsAlloc; c.masksPerBlock = E.masksPerBlock;
         c.tileGroups = nActive > 0 ? (nActive + 7) / 8 : 1;
         return c;
@@ -874,7 +887,7 @@ struct Batch {
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
             D4GParseOut po = {dTok, dU, dStates, dRefs, dTokRef};
-            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, E.dErrors, chunkPool);
+            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, errors(), chunkPool);
             stats.kernel_launches++;
             // 4. decoded bytes
             D4GTokRange* dRanges = (D4GTokRange*)rt_malloc(ranges.size() * sizeof(D4GTokRange));
@@ -1089,9 +1102,9 @@ struct Batch {
 
     void check_device_errors() {
         int32_t e = 0;
-        rt_d2h(&e, engine().dErrors, 4);
+        rt_d2h(&e, errors(), 4);
         if (e != 0) {
-            rt_memset(engine().dErrors, 0, 4);
+            rt_memset(errors(), 0, 4);
             rt_sync();
             throw std::runtime_error("device consistency check failed (" + std::to_string(e) + " errors)");
         }

@@ -108,7 +108,7 @@ struct LzFront {
         e1.record();
         // ---- 2. parse: speculative pass over every chunk, then exact re-runs until entry == predecessor's exit ----
         LzCtx c;
-        c.streams = dStreamsLz; c.S16 = dS16; c.rank16 = dRank; c.bstart = dBstart; c.errors = E.dErrors;
+        c.streams = dStreamsLz; c.S16 = dS16; c.rank16 = dRank; c.bstart = dBstart; c.errors = B.errors();
         c.meta = nullptr; c.chunkTok = nullptr;
         if (metaTot > 0) {
             dMeta = (LzChunkMeta*)rt_malloc((size_t)metaTot * sizeof(LzChunkMeta));

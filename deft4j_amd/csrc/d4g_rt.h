@@ -20,6 +20,23 @@
     } while (0)
 
 #define RT_MAX_LANES 8
+#include <mutex>
+#include <vector>
+// Process-wide state: the selected device and the lock of everything host threads share (the memory pool, the list of
+// per-thread stream sets).  Batches are driven by whichever host thread calls in — CompressionUtil's pool threads
+// (C/CompressionUtil.java:111-117), or two bench threads keeping two batches in flight — and each thread gets its own
+// HIP streams, so independent batches overlap on the device instead of queueing behind one library-wide lock.
+struct RtGlobals;
+struct RtProcess {
+    int device = -1;
+    bool ready = false;
+    std::mutex mu;
+    std::vector<RtGlobals*> threads;
+};
+inline RtProcess& rtp() {
+    static RtProcess p;
+    return p;
+}
 struct RtGlobals {
     // "lane" k = a pair of HIP streams: state ops on a[k], header searches on b[k].  Groups of deflate
     // blocks run their level sequences on different lanes so that one group's launch tails overlap
@@ -27,12 +44,42 @@ struct RtGlobals {
     hipStream_t a[RT_MAX_LANES] = {nullptr};
     hipStream_t b[RT_MAX_LANES] = {nullptr};
     int cur = 0;
-    int device = -1;
-    bool ready = false;
+    bool made = false;
+    int& device;
+    bool& ready;
+    RtGlobals() : device(rtp().device), ready(rtp().ready) {
+        std::lock_guard<std::mutex> lk(rtp().mu);
+        rtp().threads.push_back(this);
+    }
+    ~RtGlobals() {
+        destroy_streams();
+        std::lock_guard<std::mutex> lk(rtp().mu);
+        auto& v = rtp().threads;
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == this) { v.erase(v.begin() + i); break; }
+    }
+    void ensure() {   // the calling thread's streams, created on first use after d4g_init
+        if (made || !ready) return;
+        RT_CHECK(hipSetDevice(device));
+        for (int k = 0; k < RT_MAX_LANES; k++) {
+            RT_CHECK(hipStreamCreateWithFlags(&a[k], hipStreamNonBlocking));
+            RT_CHECK(hipStreamCreateWithFlags(&b[k], hipStreamNonBlocking));
+        }
+        made = true;
+    }
+    void destroy_streams() {
+        if (!made) return;
+        for (int k = 0; k < RT_MAX_LANES; k++) {
+            if (a[k]) { (void)hipStreamDestroy(a[k]); a[k] = nullptr; }
+            if (b[k]) { (void)hipStreamDestroy(b[k]); b[k] = nullptr; }
+        }
+        made = false;
+    }
     hipStream_t& stream_ref() { return a[cur]; }
 };
 inline RtGlobals& rt() {
-    static RtGlobals g;
+    thread_local RtGlobals g;
+    g.ensure();
     return g;
 }
 // Device memory comes from a small caching pool: hipMalloc / hipFree cost milliseconds for the buffers a batch
@@ -56,6 +103,7 @@ inline RtPool& rt_pool() {
     return p;
 }
 inline void* rt_malloc(size_t n) {
+    std::lock_guard<std::mutex> lk(rtp().mu);
     RtPool& P = rt_pool();
     size_t c = RtPool::size_class(n ? n : 16);
     auto it = P.freeBlocks.find(c);
@@ -80,6 +128,7 @@ inline void* rt_malloc(size_t n) {
 }
 inline void rt_free(void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(rtp().mu);
     RtPool& P = rt_pool();
     auto it = P.capacity.find(p);
     if (it == P.capacity.end()) { (void)hipFree(p); return; }
@@ -89,6 +138,7 @@ inline void rt_free(void* p) {
     P.heldBytes += c;
 }
 inline void rt_pool_release() {   // d4g_shutdown
+    std::lock_guard<std::mutex> lk(rtp().mu);
     RtPool& P = rt_pool();
     for (auto& kv : P.freeBlocks) { P.capacity.erase(kv.second); (void)hipFree(kv.second); }
     P.freeBlocks.clear();

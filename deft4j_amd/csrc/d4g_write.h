@@ -63,6 +63,41 @@ __device__ void t0_canonical_codes(const uint8_t* lens, int n, uint16_t* codes) 
     }
 }
 
+// the same by the whole workgroup: symbol i's code = first code of its length + how many lower-numbered symbols share the length
+__device__ __forceinline__ void wg_canonical_codes(const uint8_t* lens, int n, uint16_t* codes, unsigned* cnt, unsigned* nextc) {
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cnt[lens[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned next = 0;
+        int lastShift = 0;
+        nextc[0] = 0;
+        for (int l = 1; l <= 15; l++) {
+            nextc[l] = 0;
+            if (cnt[l]) {
+                next <<= (l - lastShift);
+                lastShift = l;
+                nextc[l] = next;
+                next += cnt[l];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int l = lens[i];
+        unsigned r = 0;
+        if (l) {
+            unsigned rank = 0;
+            for (int j = 0; j < i; j++) rank += lens[j] == l;
+            const unsigned code = nextc[l] + rank;
+            for (int b = 0; b < l; b++) r |= ((code >> b) & 1u) << (l - 1 - b);
+        }
+        codes[i] = (uint16_t)r;
+    }
+    __syncthreads();
+}
+
 // Output words a wave assembles in LDS per step of 64 tokens before it touches memory: interior words are written with one
 // plain store each, only the two words it may share with its neighbours go through atomicOr.  64 tokens x 48 bits fit;
 // a step that holds more (several long back-references expanded to literals) falls back to per-token atomics.
@@ -82,6 +117,7 @@ struct D4GWriteLds {
     uint16_t clCode[20];
     long long scan[16];
     long long base;
+    unsigned cnt[3][16], next[3][16];   // per alphabet: symbols per code length, first code of each length
     uint32_t stage[16][D4G_STAGE_WORDS + 2];   // per wave: the output words of its current 64 tokens
 };
 
@@ -112,40 +148,70 @@ __global__ void __launch_bounds__(1024) k_write(D4GCtx c, const D4GWriteJob* job
     __syncthreads();
     wg_copy_words((uint32_t*)S, (const uint32_t*)state_ptr(c, job.blk, 0), (int)(sizeof(D4GState) / 4));
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (S->type == D4G_FIXED) { S->litLen[286] = 8; S->litLen[287] = 8; }  // RFC 1951 fixed code is canonical over 288 symbols
-        t0_canonical_codes(S->litLen, D4G_NLIT, W.litCode);
-        t0_canonical_codes(S->distLen, D4G_NDIST, W.distCode);
-        long long pos = job.bitStart;
-        put_bits(out, pos, (uint64_t)((S->type << 1) | (job.isFinal ? 1 : 0)), 3);
-        pos += 3;
-        if (S->type == D4G_DYNAMIC) {
-            t0_canonical_codes(S->clLen, 19, W.clCode);
-            put_bits(out, pos, (uint64_t)(S->nLit - 257), 5); pos += 5;
-            put_bits(out, pos, (uint64_t)(S->nDist - 1), 5); pos += 5;
-            put_bits(out, pos, (uint64_t)(S->nCl - 4), 4); pos += 4;
-            for (int i = 0; i < S->nCl; i++) { put_bits(out, pos, S->clLen[D4G_CL_ORDER[i]], 3); pos += 3; }
-            for (int i = 0; i < S->nPairs; i++) {
-                int sym, run, value;
-                uint16_t p = S->pairs[i];
-                pair_decode(p, sym, run, value);
-                if (p & D4G_PAIR_EXPANDED) {
-                    for (int k = 0; k < run; k++) { put_bits(out, pos, W.clCode[value], S->clLen[value]); pos += S->clLen[value]; }
-                } else {
-                    put_bits(out, pos, W.clCode[sym], S->clLen[sym]); pos += S->clLen[sym];
-                    if (sym == 16) { put_bits(out, pos, (uint64_t)(run - 3), 2); pos += 2; }
-                    else if (sym == 17) { put_bits(out, pos, (uint64_t)(run - 3), 3); pos += 3; }
-                    else if (sym == 18) { put_bits(out, pos, (uint64_t)(run - 11), 7); pos += 7; }
+    // ---- codes and header, by the whole workgroup ----
+    if (threadIdx.x == 0 && S->type == D4G_FIXED) { S->litLen[286] = 8; S->litLen[287] = 8; }  // RFC 1951 fixed code is canonical over 288 symbols
+    __syncthreads();
+    wg_canonical_codes(S->litLen, D4G_NLIT, W.litCode, W.cnt[0], W.next[0]);
+    wg_canonical_codes(S->distLen, D4G_NDIST, W.distCode, W.cnt[1], W.next[1]);
+    if (S->type == D4G_DYNAMIC) wg_canonical_codes(S->clLen, 19, W.clCode, W.cnt[2], W.next[2]);
+    {
+        // header fields: prolog, then (dynamic) HLIT / HDIST / HCLEN, the code-length code lengths and the RLE pairs; every
+        // thread owns one field, a workgroup scan gives its bit offset
+        const int nCl = S->type == D4G_DYNAMIC ? S->nCl : 0, nPairs = S->type == D4G_DYNAMIC ? S->nPairs : 0;
+        const int nFields = 1 + (S->type == D4G_DYNAMIC ? 3 : 0) + nCl + nPairs;
+        long long hdrTotal = 0;
+        for (int f0 = 0; f0 < nFields; f0 += blockDim.x) {
+            const int f = f0 + threadIdx.x;
+            uint64_t bits = 0;
+            int n = 0, expRun = 0, expVal = 0;
+            if (f < nFields) {
+                if (f == 0) { bits = (uint64_t)((S->type << 1) | (job.isFinal ? 1 : 0)); n = 3; }
+                else if (S->type == D4G_DYNAMIC) {
+                    if (f == 1) { bits = (uint64_t)(S->nLit - 257); n = 5; }
+                    else if (f == 2) { bits = (uint64_t)(S->nDist - 1); n = 5; }
+                    else if (f == 3) { bits = (uint64_t)(S->nCl - 4); n = 4; }
+                    else if (f < 4 + nCl) { bits = S->clLen[D4G_CL_ORDER[f - 4]]; n = 3; }
+                    else {
+                        int sym, run, value;
+                        const uint16_t pr = S->pairs[f - 4 - nCl];
+                        pair_decode(pr, sym, run, value);
+                        if (pr & D4G_PAIR_EXPANDED) { expRun = run; expVal = value; n = run * S->clLen[value]; }
+                        else {
+                            bits = W.clCode[sym];
+                            n = S->clLen[sym];
+                            if (sym == 16) { bits |= (uint64_t)(run - 3) << n; n += 2; }
+                            else if (sym == 17) { bits |= (uint64_t)(run - 3) << n; n += 3; }
+                            else if (sym == 18) { bits |= (uint64_t)(run - 11) << n; n += 7; }
+                        }
+                    }
                 }
             }
-            if (pos != job.bitStart + 3 + S->hdrBits) {
+            long long incl = n;
+            for (int d = 1; d < 64; d <<= 1) {
+                long long o = __shfl_up(incl, d);
+                if ((int)(threadIdx.x & 63) >= d) incl += o;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 63) W.scan[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            long long waveBase = 0, total = 0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); i++) { if (i < (int)(threadIdx.x >> 6)) waveBase += W.scan[i]; total += W.scan[i]; }
+            long long pos = job.bitStart + hdrTotal + waveBase + incl - n;
+            if (expRun) {
+                for (int k = 0; k < expRun; k++) { put_bits(out, pos, W.clCode[expVal], S->clLen[expVal]); pos += S->clLen[expVal]; }
+            } else put_bits(out, pos, bits, n);
+            hdrTotal += total;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (S->type == D4G_DYNAMIC && hdrTotal != 3 + S->hdrBits) {
 #ifdef D4G_HOSTSIM
-                fprintf(stderr, "write: header wrote %lld bits, state says %lld\n", pos - job.bitStart - 3, (long long)S->hdrBits);
+                fprintf(stderr, "write: header wrote %lld bits, state says %lld\n", hdrTotal - 3, (long long)S->hdrBits);
 #endif
                 atomicAdd(c.errors, 1);
             }
+            W.base = job.bitStart + hdrTotal;
         }
-        W.base = pos;
     }
     __syncthreads();
     const uint64_t* mask = mask_ptr(c, b, S->maskSlot);

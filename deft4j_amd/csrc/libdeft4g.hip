@@ -24,7 +24,16 @@ struct d4g_batch {
 };
 
 namespace {
-std::mutex g_mu;  // CompressionUtil calls in from a thread pool (C/CompressionUtil.java:111-117): serialise
+// CompressionUtil calls in from a thread pool (C/CompressionUtil.java:111-117).  d4g_init / d4g_shutdown are exclusive;
+// everything else runs concurrently: a batch belongs to the thread that is calling with it, every host thread has its own
+// HIP streams (d4g_rt.h) and the shared pieces (memory pool, engine set-up) take their own locks.  The test-only CPU
+// emulator is single-threaded, so its build keeps one library-wide lock.
+std::mutex g_mu;
+#ifdef D4G_HOSTSIM
+#define D4G_API_LOCK() std::lock_guard<std::mutex> lk(g_mu)
+#else
+#define D4G_API_LOCK() do { } while (0)
+#endif
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -56,14 +65,11 @@ int d4g_init(int device_index) {
         if (rt().ready && rt().device != device_index)
             return fail(D4G_ERR_ARG, "already initialised on device " + std::to_string(rt().device) + ": call d4g_shutdown() before selecting another device");
         RT_CHECK(hipSetDevice(device_index));
-        for (int k = 0; k < RT_MAX_LANES; k++) {
-            if (!rt().a[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().a[k], hipStreamNonBlocking));
-            if (!rt().b[k]) RT_CHECK(hipStreamCreateWithFlags(&rt().b[k], hipStreamNonBlocking));
-        }
         rt().device = device_index;
         if (const char* mb = getenv("D4G_POOL_MAX_MB")) rt_pool().maxHeldBytes = (size_t)atoll(mb) << 20;
 #endif
         rt().ready = true;
+        (void)rt();           // this thread's streams
         engine().init();
         return D4G_OK;
     } catch (const std::exception& ex) {
@@ -80,9 +86,10 @@ void d4g_shutdown(void) {
         engine().release();
 #ifndef D4G_HOSTSIM
         rt_pool_release();
-        for (int k = 0; k < RT_MAX_LANES; k++) {
-            if (rt().a[k]) { (void)hipStreamDestroy(rt().a[k]); rt().a[k] = nullptr; }
-            if (rt().b[k]) { (void)hipStreamDestroy(rt().b[k]); rt().b[k] = nullptr; }
+        {   // every host thread's streams (no batch may be running: shutdown is exclusive by contract)
+            std::vector<RtGlobals*> all;
+            { std::lock_guard<std::mutex> lk2(rtp().mu); all = rtp().threads; }
+            for (RtGlobals* g : all) g->destroy_streams();
         }
         rt().device = -1;
 #endif
@@ -92,7 +99,7 @@ void d4g_shutdown(void) {
 }
 
 d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
     try {
         bind_device();
@@ -106,7 +113,7 @@ d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in
 }
 
 int d4g_batch_run(d4g_batch* b, int merge_blocks) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
     if (b->lz) return fail(D4G_ERR_ARG, "encoder batch: use d4g_batch_run_encode");
@@ -121,7 +128,7 @@ int d4g_batch_run(d4g_batch* b, int merge_blocks) {
 
 d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const size_t* raw_len, size_t n_out,
                                    const d4g_encoder_spec* spec) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
     if ((n_in && (!raw || !raw_len)) || (n_out && !spec)) { fail(D4G_ERR_ARG, "null argument"); return nullptr; }
     try {
@@ -138,7 +145,7 @@ d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const
 }
 
 int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b || !b->lz) return fail(D4G_ERR_ARG, "not an encoder batch");
     try {
@@ -192,7 +199,7 @@ int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* sa
 }
 
 int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
     const Batch* owner = nullptr;
@@ -209,7 +216,7 @@ int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
 }
 
 int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, size_t* len) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     const HStream& s = b->impl.streams[i];
     if (s.status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
@@ -226,7 +233,7 @@ int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, siz
 }
 
 int d4g_batch_parse(d4g_batch* b) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
     try {
@@ -243,7 +250,7 @@ int d4g_batch_parse(d4g_batch* b) {
 }
 
 int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler32, int64_t* isize) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
     try {
@@ -266,7 +273,7 @@ int d4g_batch_stats(d4g_batch* b, d4g_stats* st) {
 }
 
 void d4g_batch_destroy(d4g_batch* b) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     try { bind_device(); } catch (const std::exception&) {}
     delete b;
 }
@@ -321,7 +328,7 @@ int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
     if (!b) return D4G_ERR_RUNTIME;
     int rc;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
+        D4G_API_LOCK();
         try {
             bind_device();
             engine().init();
@@ -347,7 +354,7 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
     if (!b) return D4G_ERR_RUNTIME;
     int rc;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
+        D4G_API_LOCK();
         try {
             bind_device();
             engine().init();
@@ -550,7 +557,7 @@ int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int
     (void)iter;
     if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; if (winner) winner[i] = -1; }
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     try {
         bind_device();
@@ -632,7 +639,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
 
 int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks) {
     (void)iter;
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b || b->lz) return fail(D4G_ERR_ARG, "not a batch of deflate streams");
     try {
@@ -717,13 +724,13 @@ long long d4g_test_pack_kinds(void) {
 #ifdef D4G_PROFILE_OPS
 // profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
 int d4g_debug_set_experiment(long long mode) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     rt_h2d(engine().dOpStats + 63, &mode, 8);
     rt_sync();
     return 0;
 }
 int d4g_debug_opstats(long long* out64) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    D4G_API_LOCK();
     rt_d2h(out64, engine().dOpStats, 64 * 8);
     (void)hipMemcpyFromSymbol(out64 + 56, HIP_SYMBOL(d4g_dbg_counters), 7 * 8);
     (void)hipMemcpyFromSymbol(out64 + 28, HIP_SYMBOL(d4g_dbg_hdr), 4 * 8);

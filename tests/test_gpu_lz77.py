@@ -164,3 +164,22 @@ def test_mode_cheap_batch_of_members(D):
         ngraft += g
     assert ngraft >= 12          # every zlib-6 member is beaten by its recompression
     b.close()
+
+
+def test_gzip_file_through_mode_cheap(D):
+    """`deft4j optimise --mode=CHEAP` on a gzip file (M/CMDUtil.java:57-116 over K/GZFile.java): a weakly compressed
+    member is recompressed, grafted, and the container re-written with a recomputed trailer; the transcript carries the
+    reference's recompression lines."""
+    import gzip
+    import oracle_compose as OC
+    from deft4j_amd import containers
+    text = zlib.decompress(rd("asyoulik_asyoulik-gzip.s00.in.deflate"), -15)
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15)
+    payload = c1.compress(text) + c1.flush()
+    gz = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\x03" + payload + (zlib.crc32(text) & 0xffffffff).to_bytes(4, "little") + (len(text) & 0xffffffff).to_bytes(4, "little")
+    (out, lines), = containers.optimise_files([gz], True, mode=D.MODE_CHEAP)
+    assert gzip.decompress(out) == text
+    want = OC.recompress(payload, True)
+    assert want["recompress_saved"] > 0
+    assert out[10:-8] == want["out"]
+    assert any(l.startswith("Recompressed stream 0") for l in lines) and lines[-1] == "Saved %d bits with recompression" % want["recompress_saved"]
