@@ -325,7 +325,11 @@ struct Program {
             // token-pass-only ops (no single-lane section) go to the wide-workgroup launch
             std::vector<int> narrow, wide;
             for (int id : stateLevels[l])
-                (wide_block() > 0 && (ops[id].kind == OP_OPT || ops[id].kind == OP_LEAST) ? wide : narrow).push_back(id);
+                {
+                    // D4G_WIDE_KINDS: bit k set = ops of kind k run in the wide launch (default: the token-pass-only kinds)
+                    static const int wideKinds = env_int("D4G_WIDE_KINDS", (1 << OP_OPT) | (1 << OP_LEAST));
+                    (wide_block() > 0 && ((wideKinds >> ops[id].kind) & 1) ? wide : narrow).push_back(id);
+                }
             stateOff.push_back({lists.size(), (int)narrow.size()});
             lists.insert(lists.end(), narrow.begin(), narrow.end());
             wideOff.push_back({lists.size(), (int)wide.size()});

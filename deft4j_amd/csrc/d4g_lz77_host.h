@@ -12,6 +12,15 @@ namespace d4g {
 
 struct LzSpec { int32_t input, encoder, strategy; };   // mirrors d4g_encoder_spec (include/deft4g.h)
 
+// device buffers of the front end that must not outlive it: released before the batch's own phases start, and by the
+// destructor when an exception unwinds the front end
+struct LzScratch {
+    std::vector<void*> v;
+    template <typename T> T* own(T* p) { v.push_back((void*)p); return p; }
+    void release() { for (void* p : v) rt_free(p); v.clear(); }
+    ~LzScratch() { release(); }
+};
+
 struct LzFront {
     Batch& B;
     std::vector<LzSpec> specs;
@@ -86,7 +95,8 @@ struct LzFront {
         for (size_t i = 0; i < nIn; i++)
             if (needSort[i])
                 for (i64 b = 0; b * LZ_SORT_BLOCK < rawLen[i]; b++) sortJobs.push_back({(int32_t)i, (int32_t)b});
-        LzStream* dStreamsLz = (LzStream*)rt_malloc(nIn * sizeof(LzStream) + 16);
+        LzScratch tmp;
+        LzStream* dStreamsLz = tmp.own((LzStream*)rt_malloc(nIn * sizeof(LzStream) + 16));
         rt_h2d(dStreamsLz, hs.data(), nIn * sizeof(LzStream));
         uint16_t *dS16 = nullptr, *dRank = nullptr, *dBstart = nullptr;
         LzChunkMeta* dMeta = nullptr;
@@ -95,9 +105,9 @@ struct LzFront {
         RtEvent e0, e1, e2;
         e0.record();
         if (!sortJobs.empty()) {
-            dS16 = (uint16_t*)rt_malloc((size_t)posTot * 2 + 64);
-            dRank = (uint16_t*)rt_malloc((size_t)posTot * 2 + 64);
-            dBstart = (uint16_t*)rt_malloc((size_t)posTot * 2 + 64);   // 32768 entries per sort block
+            dS16 = tmp.own((uint16_t*)rt_malloc((size_t)posTot * 2 + 64));
+            dRank = tmp.own((uint16_t*)rt_malloc((size_t)posTot * 2 + 64));
+            dBstart = tmp.own((uint16_t*)rt_malloc((size_t)posTot * 2 + 64));   // 32768 entries per sort block
             LzSortJob* dJobs = (LzSortJob*)rt_malloc(sortJobs.size() * sizeof(LzSortJob));
             rt_h2d(dJobs, sortJobs.data(), sortJobs.size() * sizeof(LzSortJob));
             RT_LAUNCH(k_lz_sort, sortJobs.size(), LZ_SORT_THREADS, dStreamsLz, dJobs, dS16, dRank, dBstart);
@@ -111,8 +121,8 @@ struct LzFront {
         c.streams = dStreamsLz; c.S16 = dS16; c.rank16 = dRank; c.bstart = dBstart; c.errors = B.errors();
         c.meta = nullptr; c.chunkTok = nullptr;
         if (metaTot > 0) {
-            dMeta = (LzChunkMeta*)rt_malloc((size_t)metaTot * sizeof(LzChunkMeta));
-            dChunkTok = (uint32_t*)rt_malloc((size_t)metaTot * (LZ_CHUNK + 2) * 4 + 64);
+            dMeta = tmp.own((LzChunkMeta*)rt_malloc((size_t)metaTot * sizeof(LzChunkMeta)));
+            dChunkTok = tmp.own((uint32_t*)rt_malloc((size_t)metaTot * (LZ_CHUNK + 2) * 4 + 64));
             c.meta = dMeta; c.chunkTok = dChunkTok;
             std::vector<LzParseJob> jobs;
             std::vector<int32_t> chunkIndex((size_t)metaTot), chunkParse((size_t)metaTot);
@@ -281,9 +291,9 @@ struct LzFront {
         B.dRefs = (uint4*)rt_malloc((size_t)refTot * 16 + 64);
         B.dTokRef = (uint32_t*)rt_malloc((size_t)tokTot * 4 + 64);
         const size_t nBlk = blocks.size();
-        LzOutStream* dOuts = (LzOutStream*)rt_malloc(nOut * sizeof(LzOutStream) + 16);
-        LzBlockDesc* dBlk = (LzBlockDesc*)rt_malloc(nBlk * sizeof(LzBlockDesc) + 16);
-        LzFillJob* dFill = (LzFillJob*)rt_malloc(fillJobs.size() * sizeof(LzFillJob) + 16);
+        LzOutStream* dOuts = tmp.own((LzOutStream*)rt_malloc(nOut * sizeof(LzOutStream) + 16));
+        LzBlockDesc* dBlk = tmp.own((LzBlockDesc*)rt_malloc(nBlk * sizeof(LzBlockDesc) + 16));
+        LzFillJob* dFill = tmp.own((LzFillJob*)rt_malloc(fillJobs.size() * sizeof(LzFillJob) + 16));
         rt_h2d(dOuts, outs.data(), nOut * sizeof(LzOutStream));
         rt_h2d(dBlk, blocks.data(), nBlk * sizeof(LzBlockDesc));
         rt_h2d(dFill, fillJobs.data(), fillJobs.size() * sizeof(LzFillJob));
@@ -297,8 +307,8 @@ struct LzFront {
             else { d.uLen = 0; d.refCount = 0; }
         rt_h2d(dBlk, blocks.data(), nBlk * sizeof(LzBlockDesc));
         // ---- 5. per block: zlib's trees and block type, and the block's state ----
-        D4GState* dTmpStates = (D4GState*)rt_malloc(nBlk * sizeof(D4GState) + 16);
-        LzBlockOut* dBo = (LzBlockOut*)rt_malloc(nBlk * sizeof(LzBlockOut) + 16);
+        D4GState* dTmpStates = tmp.own((D4GState*)rt_malloc(nBlk * sizeof(D4GState) + 16));
+        LzBlockOut* dBo = tmp.own((LzBlockOut*)rt_malloc(nBlk * sizeof(LzBlockOut) + 16));
         std::vector<LzBlockOut> bo(nBlk);
         if (nBlk) {
             RT_LAUNCH(k_lz_blocks, nBlk, 64, dStreamsLz, dOuts, dBlk, (int)nBlk, B.dTok, dTmpStates, dBo);
@@ -356,8 +366,7 @@ struct LzFront {
         B.stats.ms_lz_emit = rt_elapsed_ms(e3, e4);
         B.stats.lz_symbols = 0;
         for (size_t oi = 0; oi < nOut; oi++) B.stats.lz_symbols += outSyms[oi];
-        rt_free(dStreamsLz); rt_free(dS16); rt_free(dRank); rt_free(dBstart); rt_free(dMeta); rt_free(dChunkTok);
-        rt_free(dOuts); rt_free(dBlk); rt_free(dFill); rt_free(dTmpStates); rt_free(dBo);
+        tmp.release();   // the sort arrays, chunk tokens and block tables are done with: the candidate search needs the memory
         B.check_device_errors();
         double t1 = now_ms();
         if (optimise) B.phase1();
