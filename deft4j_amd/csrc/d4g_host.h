@@ -78,6 +78,18 @@ static inline int exec_persistent(int nActive = 0) {
     if (mode == 2) return nActive <= maxBlocks ? 1 : 0;
     return mode;
 }
+// threads per workgroup of the block decoders (probe / emit): a batch is that many 512-bit chunks decoded side by side
+static inline int parse_threads() {
+#ifdef D4G_HOSTSIM
+    const char* e = getenv("D4G_SIM_PARSE_THREADS");   // the emulator's fibers are slow: one wave unless a test asks for more
+    int v = e ? atoi(e) : 64;
+#else
+    const char* e = getenv("D4G_PARSE_THREADS");
+    int v = e ? atoi(e) : 512;
+#endif
+    if (v != 64 && v != 128 && v != 256 && v != 512) v = 64;
+    return v;
+}
 static inline int env_int(const char* name, int def) {
     const char* t = getenv(name);
     return t ? atoi(t) : def;
@@ -643,11 +655,11 @@ struct Batch {
             if (nc) {
                 D4GProbeHit* dHits = (D4GProbeHit*)rt_malloc((size_t)nc * sizeof(D4GProbeHit));
                 rt_memset(dN, 0, 4);
-                chunkPool.cap = (unsigned)std::min<i64>(1 << 30, totalBytes * 8 / (64 * D4G_CHUNK_BITS) + 2 * (i64)nc + 64);
+                chunkPool.cap = (unsigned)std::min<i64>(1 << 30, totalBytes * 8 / (64 * D4G_CHUNK_BITS) + 2 * (i64)nc * (parse_threads() / 64) + 64);   // one record per wave and batch
                 chunkPool.batches = (D4GChunkBatch*)rt_malloc((size_t)chunkPool.cap * sizeof(D4GChunkBatch));
                 chunkPool.next = (unsigned*)rt_malloc(16);
                 rt_memset(chunkPool.next, 0, 16);
-                RT_LAUNCH(k_probe_blocks, nc, 64, dStreams, dCands, (D4GProbeOut*)nullptr, nc, dHits, dN, chunkPool);
+                RT_LAUNCH(k_probe_blocks, nc, parse_threads(), dStreams, dCands, (D4GProbeOut*)nullptr, nc, dHits, dN, chunkPool);
                 stats.kernel_launches++;
                 unsigned nh = 0;
                 rt_d2h(&nh, dN, 4);
@@ -701,7 +713,7 @@ struct Batch {
             }
             if (ex.empty()) break;
             rt_h2d(dEx, ex.data(), ex.size() * sizeof(D4GProbeIn));
-            RT_LAUNCH(k_probe_blocks, ex.size(), 64, dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GProbeHit*)nullptr, (unsigned*)nullptr,
+            RT_LAUNCH(k_probe_blocks, ex.size(), parse_threads(), dStreams, dEx, dExOut, (unsigned)ex.size(), (D4GProbeHit*)nullptr, (unsigned*)nullptr,
                       D4GChunkPool{nullptr, nullptr, 0u});
             stats.kernel_launches++;
             stats.exact_probes += (i64)ex.size();
@@ -891,7 +903,7 @@ struct Batch {
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
             rt_h2d(dEm, emits.data(), emits.size() * sizeof(D4GEmitIn));
             D4GParseOut po = {dTok, dU, dStates, dRefs, dTokRef};
-            RT_LAUNCH(k_emit_blocks, emits.size(), 64, dStreams, dEm, po, errors(), chunkPool);
+            RT_LAUNCH(k_emit_blocks, emits.size(), parse_threads(), dStreams, dEm, po, errors(), chunkPool);
             stats.kernel_launches++;
             // 4. decoded bytes
             D4GTokRange* dRanges = (D4GTokRange*)rt_malloc(ranges.size() * sizeof(D4GTokRange));

@@ -378,11 +378,9 @@ __global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, co
 
 // chunks whose entry state is not their predecessor's exit state (one thread per chunk; list compacted by atomics —
 // order does not matter, every listed chunk is re-run independently)
-__global__ void k_lz_check(const LzChunkMeta* meta, const int32_t* chunkStream, const int32_t* chunkIndex, int nChunksTotal, int32_t* redo,
-                           unsigned* nRedo) {
+__global__ void k_lz_check(const LzChunkMeta* meta, const int32_t* chunkIndex, int nChunksTotal, int32_t* redo, unsigned* nRedo) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nChunksTotal) return;
-    (void)chunkStream;
     if (chunkIndex[i] == 0) return;
     if (meta[i].entry != meta[i - 1].exit) redo[atomicAdd(nRedo, 1u)] = i;
 }

@@ -143,7 +143,7 @@ struct LzFront {
             for (int pass = 0;; pass++) {
                 if (pass > 100000) throw std::runtime_error("lz77 parse did not converge");
                 rt_memset(dN, 0, 4);
-                RT_LAUNCH(k_lz_check, (metaTot + 255) / 256, 256, dMeta, dIdx, dIdx, (int)metaTot, dRedo, dN);
+                RT_LAUNCH(k_lz_check, (metaTot + 255) / 256, 256, dMeta, dIdx, (int)metaTot, dRedo, dN);
                 B.stats.kernel_launches++;
                 unsigned nr = 0;
                 rt_d2h(&nr, dN, 4);

@@ -69,7 +69,7 @@ struct D4GEmitIn {
     int32_t pad;
 };
 #define D4G_LUT_BITS 10
-#define D4G_INCH 8192
+#define D4G_INCH 33024   // staged input: one batch of 512 chunks of D4G_CHUNK_BITS (32 KiB) plus the overshoot of the last token
 
 struct D4GDecTab {          // canonical decoder of one alphabet
     uint16_t lut[1 << D4G_LUT_BITS];  // sym | len<<9, 0xffff = use the bit-serial path
@@ -80,10 +80,17 @@ struct D4GDecTab {          // canonical decoder of one alphabet
     int nCodes;
 };
 
+#define D4G_PARSE_MAXTHREADS 512
 struct D4GParseLds {
     D4GState st;
     D4GDecTab lit, dist, cl;
     alignas(16) uint8_t inbuf[D4G_INCH + 16];
+    // workgroup-wide exchange of the chunk decoders: exits / stop flags, per-wave scan totals, broadcasts
+    int xExit[D4G_PARSE_MAXTHREADS], xFlag[D4G_PARSE_MAXTHREADS];
+    unsigned wsN[8], wsU[8], wsR[8], wsB[8];
+    int wsM[8];
+    int anyDirty, firstStop;
+    long long bc;
 };
 
 // Bit reader owned by lane 0 (B/io/BitInputStream.java:59-82: LSB-first).
@@ -135,7 +142,7 @@ struct D4GBitReader {
 #ifndef D4G_CHUNK_BITS
 #define D4G_CHUNK_BITS 512   // bits per lane and pass of the wave-wide token decoder
 #endif
-static_assert(64 * D4G_CHUNK_BITS + 160 <= (D4G_INCH + 16) * 8, "a batch of 64 chunks must fit the staged input window");
+static_assert(512 * D4G_CHUNK_BITS + 160 <= (D4G_INCH + 16) * 8, "a batch of 512 chunks must fit the staged input window");
 static_assert(D4G_CHUNK_BITS + 48 < 1024, "tokens per chunk must fit the 10-bit field of a chunk record");
 // 64 bits of the staged input starting at bit `posRel` (any lane, any position inside the staged chunk)
 __device__ __forceinline__ uint64_t d4g_peek64(const uint8_t* inbuf, int posRel) {
@@ -150,7 +157,7 @@ __device__ __forceinline__ uint64_t d4g_peek64(const uint8_t* inbuf, int posRel)
 // Huffman.buildCodes (B/huffman/Huffman.java:35-64) + decoder tables.  Lane 0 prepares the
 // canonical structure, all lanes fill the LUT.
 __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
-    int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x, nl = blockDim.x;   // every thread of the workgroup helps to fill the table
     __syncthreads();
     if (lane == 0) {
         for (int l = 0; l < 16; l++) { T->count[l] = 0; T->first[l] = 0; T->offs[l] = 0; }
@@ -177,12 +184,12 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
         for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) T->sorted[fill[lens[i]]++] = (uint16_t)i;
     }
     __syncthreads();
-    for (int i = lane; i < (1 << D4G_LUT_BITS); i += 64) T->lut[i] = 0xffff;
+    for (int i = lane; i < (1 << D4G_LUT_BITS); i += nl) T->lut[i] = 0xffff;
     __syncthreads();
     if (T->useLut) {
         for (int l = 1; l <= D4G_LUT_BITS; l++) {
             int cnt = T->count[l];
-            for (int k = lane; k < cnt; k += 64) {
+            for (int k = lane; k < cnt; k += nl) {
                 int code = T->first[l] + k;
                 int sym = T->sorted[T->offs[l] + k];
                 unsigned r = 0;
@@ -428,30 +435,37 @@ template <bool EMIT>
 __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long long bitPos, int strict, D4GProbeOut& po,
                                 const D4GEmitIn* em, const D4GParseOut& out, const D4GChunkPool& pool) {
     __shared__ D4GParseLds L;
-    int lane = threadIdx.x & 63;
-    D4GBitReader br;
+    const int tid = threadIdx.x, NL = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NL >> 6;
+    D4GBitReader br;   // thread 0's
     br.inBase = 0;
     br.nbits = sd.len * 8;
     br.rel = 0; br.posRel = 0; br.limitRel = 0; br.buf = 0; br.cnt = 0;
     D4GState* S = &L.st;
+    // workgroup-wide exchange of small values (all threads call; the value of thread 0 / a reduction comes back to all)
+    auto bcast = [&](long long v) D4G_LAMBDA_INLINE {
+        __syncthreads();
+        if (tid == 0) L.bc = v;
+        __syncthreads();
+        return L.bc;
+    };
     auto stage = [&](long long bitpos) {
         long long base = (bitpos >> 3) & ~15LL;
         if (base > sd.len) base = sd.len & ~15LL;
         __syncthreads();
-        for (int i = lane * 16; i < D4G_INCH + 16; i += 64 * 16) *(uint4*)(L.inbuf + i) = *(const uint4*)(sd.data + base + i);
+        for (int i = tid * 16; i < D4G_INCH + 16; i += NL * 16) *(uint4*)(L.inbuf + i) = *(const uint4*)(sd.data + base + i);
         __syncthreads();
         br.inBase = base;
-        if (lane == 0) br.reset_to(L.inbuf, bitpos);
+        if (tid == 0) br.reset_to(L.inbuf, bitpos);
     };
     po.nRef = 0; po.firstBatch = -1;
     po.status = -1; po.type = 0; po.bfinal = 0; po.eofHit = 0; po.endBit = 0; po.nTok = 0; po.uLen = 0; po.sizeBits = 0; po.needHist = 0;
     stage(bitPos);
     long long pk = 0;
-    if (lane == 0) {
+    if (tid == 0) {
         if (!br.have(3)) pk = -1;
         else { pk = (long long)(br.buf & 7); br.skip(3); }
     }
-    pk = __shfl(pk, 0);
+    pk = bcast(pk);
     if (pk < 0) return;
     po.bfinal = (int)(pk & 1);
     int btype = (int)(pk >> 1);
@@ -461,7 +475,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     if (btype == 0) {
         // DeflateBlockUncompressed.parse — B/deflate/DeflateBlockUncompressed.java:23-36
         long long r = 0, p = 0;
-        if (lane == 0) {
+        if (tid == 0) {
             p = (br.pos() + 7) & ~7LL;
             if (p + 32 > br.nbits) r = -1;
             else {
@@ -470,13 +484,13 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                 r = nlen != ((~len) & 0xffff) ? -1 : len;
             }
         }
-        r = __shfl(r, 0);
-        p = __shfl(p, 0);
+        r = bcast(r);
+        p = bcast(p);
         if (r < 0) return;
         int len = (int)r;
         long long bytePos = (p + 32) >> 3;
         if (EMIT) {
-            for (int k = lane; k < len; k += 64) {
+            for (int k = tid; k < len; k += NL) {
                 // bytes past the end of input read as (byte)-1 in the reference (BitInputStreamUtil.readFromBIS)
                 uint8_t v = (bytePos + k < sd.len) ? sd.data[bytePos + k] : 0xff;
                 out.U[sd.uBase + em->uStart + k] = v;
@@ -489,19 +503,19 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         po.status = 0;
         return;
     }
-    for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)S)[i] = 0;
+    for (int i = tid; i < (int)(sizeof(D4GState) / 4); i += NL) ((uint32_t*)S)[i] = 0;
     __syncthreads();
     if (btype == 1) {
         // The fixed code (HuffmanTable.LIT, B/huffman/HuffmanTable.java:166-209) is the RFC 1951 code over
         // 288 symbols; 286/287 take code space but are not decodable symbols (decodeStream rejects > 285).
-        for (int i = lane; i < D4G_NLIT; i += 64) S->litLen[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-        for (int i = lane; i < D4G_NDIST; i += 64) S->distLen[i] = i < 30 ? 5 : 0;
-        if (lane == 0) S->type = D4G_FIXED;
+        for (int i = tid; i < D4G_NLIT; i += NL) S->litLen[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+        for (int i = tid; i < D4G_NDIST; i += NL) S->distLen[i] = i < 30 ? 5 : 0;
+        if (tid == 0) S->type = D4G_FIXED;
         __syncthreads();
     } else {
         // initDynamicDecoder — DeflateBlockHuffman.java:892-1010
         long long r = 0;
-        if (lane == 0) {
+        if (tid == 0) {
             if (!br.have(14)) r = -1;
             else {
                 br.fill(L.inbuf);
@@ -523,10 +537,10 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                 S->hdrBits = 5 + 5 + 4 + 3 * S->nCl;
             }
         }
-        r = __shfl(r, 0);
+        r = bcast(r);
         if (r < 0) return;
         d4g_build_decoder(&L.cl, S->clLen, 19);
-        if (lane == 0) {
+        if (tid == 0) {
             int i = 0, np = 0;
             int combined = S->nLit + S->nDist;
             while (i < combined && r == 0) {
@@ -563,27 +577,29 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
             }
             S->nPairs = np;
         }
-        r = __shfl(r, 0);
+        r = bcast(r);
         if (r < 0) return;
     }
     d4g_build_decoder(&L.lit, S->litLen, btype == 1 ? 288 : S->nLit);
     d4g_build_decoder(&L.dist, S->distLen, btype == 1 ? 30 : S->nDist);
-    if (btype == 1 && lane == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
+    if (btype == 1 && tid == 0) { S->litLen[286] = 0; S->litLen[287] = 0; }
+    __syncthreads();
     if (strict) {
         // speculative candidates must look like an encoder's output: complete literal/length code with an
         // EOB code, complete (or at most one-code) distance code
         bool good = L.lit.complete && S->litLen[256] > 0 && (L.dist.complete || L.dist.nCodes <= 1);
         if (!good) return;
     }
-    // ---- decodeStream — DeflateBlockHuffman.java:778-890, by the whole wave ----
-    // The block's bits are cut into chunks of D4G_CHUNK_BITS; 64 chunks make a batch.  Lane i decodes chunk i
-    // from a start position: lane 0 from the known token boundary, the others from a guess (their chunk's
-    // first bit).  A decoder started off a token boundary usually falls into step with the true token
-    // sequence after a few codes, so its exit position (first token boundary past the chunk's end) is
-    // usually right.  Each pass hands every lane its left neighbour's exit as the new start and re-decodes the
-    // chunks whose start changed; when a pass changes nothing, start(i+1) == exit(i) for all i and start(0) is
-    // true, so every start is a true token boundary — the check is exact, at worst after 64 passes.
-    const long long tokensStart = __shfl(br.pos(), 0);
+    // ---- decodeStream — DeflateBlockHuffman.java:778-890, by the whole workgroup ----
+    // The block's bits are cut into chunks of D4G_CHUNK_BITS; NL (= workgroup size) chunks make a batch.  Thread i
+    // decodes chunk i from a start position: thread 0 from the known token boundary, the others from a guess (their
+    // chunk's first bit).  A decoder started off a token boundary usually falls into step with the true token
+    // sequence after a few codes, so its exit position (first token boundary past the chunk's end) is usually
+    // right.  Each pass hands every thread its left neighbour's exit as the new start and re-decodes the chunks
+    // whose start changed; when a pass changes nothing, start(i+1) == exit(i) for all i and start(0) is true, so
+    // every start is a true token boundary — the check is exact, at worst after NL passes.  With 512 threads a batch
+    // is 32 KiB of input: most blocks are one batch, decoded by eight waves at once instead of one wave eight times.
+    const long long tokensStart = bcast(br.pos());
     long long s0 = tokensStart;   // true token boundary where the batch begins
     long long G = s0;             // grid origin of the batch: chunk i covers [G + i*C, G + (i+1)*C)
     unsigned nTok = 0, nU = 0, nRef = 0, litlenBits = 0;
@@ -595,7 +611,7 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     const unsigned uStart32 = EMIT ? (unsigned)em->uStart : 0u;
     long long endBit = 0;
     constexpr int C = D4G_CHUNK_BITS;
-    // one chunk: WRITE = false counts, WRITE = true also stores the tokens (the lane's output offsets are known then)
+    // one chunk: WRITE = false counts, WRITE = true also stores the tokens (the thread's output offsets are known then)
     auto decode_chunk = [&](auto writeTag, int start, int endc, int limRel, unsigned tokAt, unsigned uAt, unsigned refAt, int& exitp,
                             unsigned& n, unsigned& u, unsigned& r, unsigned& lb, int& need, int& fl) D4G_LAMBDA_INLINE {
         constexpr bool WRITE = decltype(writeTag)::value;
@@ -646,28 +662,31 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
         }
         exitp = pos;
     };
-    int recBatch = EMIT ? em->firstBatch : -1;   // emit: next recorded batch; probe: last recorded batch
+    int recBatch = EMIT ? em->firstBatch : -1;   // emit: next recorded batch (its first record); probe: last recorded batch
     int firstBatch = -1;
     bool recording = !EMIT && pool.batches != nullptr;
     const bool replay = EMIT && recBatch >= 0 && pool.batches != nullptr;
     while (true) {
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (replay) {   // the probe's verified starts and counts of this batch
-            rec = pool.batches[recBatch].rec[lane];
-            s0 = tokensStart + (long long)__shfl(rec.x, 0);
+        if (replay) {   // the probe's verified starts and counts of this batch: one record per wave, nw consecutive records
+            rec = pool.batches[recBatch + wave].rec[lane];
+            __syncthreads();
+            if (tid == 0) L.bc = (long long)rec.x;
+            __syncthreads();
+            s0 = tokensStart + L.bc;
         }
-        // the staged input must cover the batch: 64 chunks, one token of overshoot, the 12-byte window of a peek
+        // the staged input must cover the batch: NL chunks, one token of overshoot, the 12-byte window of a peek
         {
             long long baseBits = br.inBase * 8;
-            bool covers = s0 >= baseBits && (G - baseBits) + 64LL * C + 64 + 96 <= (long long)(D4G_INCH + 16) * 8;
-            if (!covers) stage(s0);   // wave-uniform decision
+            bool covers = s0 >= baseBits && (G - baseBits) + (long long)NL * C + 64 + 96 <= (long long)(D4G_INCH + 16) * 8;
+            if (!covers) stage(s0);   // workgroup-uniform decision
         }
         const long long baseBits = br.inBase * 8;
         const int Grel = (int)(G - baseBits), s0rel = (int)(s0 - baseBits);
         long long lim = br.nbits - baseBits;
         const int limRel = lim > 0x3fffffff ? 0x3fffffff : (int)lim;
-        int start = lane == 0 ? s0rel : Grel + lane * C;
-        const int endc = Grel + (lane + 1) * C;
+        int start = tid == 0 ? s0rel : Grel + tid * C;
+        const int endc = Grel + (tid + 1) * C;
         int exitp = start, need = 0, fl = 0;
         unsigned n = 0, u = 0, r = 0, lb = 0;
         bool dirty = true;
@@ -676,28 +695,56 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
             n = rec.y & 1023u; r = (rec.y >> 10) & 1023u; fl = (int)(rec.y >> 20); u = rec.z; lb = rec.w;
             need = -0x40000000;   // (the host checked the distances at probe time)
         } else {
-            for (int pass = 0; pass < 66; pass++) {
+            for (int pass = 0; pass < NL + 2; pass++) {
                 if (dirty) decode_chunk(std::false_type{}, start, endc, limRel, 0u, 0u, 0u, exitp, n, u, r, lb, need, fl);
-                int pe = __shfl_up(exitp, 1), pfl = __shfl_up(fl, 1);
-                dirty = lane > 0 && pfl == 0 && pe != start;
-                if (dirty) start = pe;
-                if (!__ballot(dirty)) break;
+                // every thread takes its left neighbour's exit (and stop flag)
+                __syncthreads();
+                L.xExit[tid] = exitp;
+                L.xFlag[tid] = fl;
+                if (tid == 0) L.anyDirty = 0;
+                __syncthreads();
+                const int pe = tid ? L.xExit[tid - 1] : exitp, pfl = tid ? L.xFlag[tid - 1] : fl;
+                dirty = tid > 0 && pfl == 0 && pe != start;
+                if (dirty) { start = pe; L.anyDirty = 1; }
+                __syncthreads();
+                if (!L.anyDirty) break;
             }
         }
-        // the block ends (or fails) in the first lane that stopped early; lanes up to it hold true tokens
-        unsigned long long tm = __ballot(fl != 0);
-        const int f = tm ? __ffsll((long long)tm) - 1 : 64;
-        const bool valid = lane <= f;
-        if (f < 64 && __shfl(fl, f) == 2) return;   // invalid code or out of input: the block does not parse
+        // the block ends (or fails) in the first thread that stopped early; threads up to it hold true tokens
+        __syncthreads();
+        if (tid == 0) L.firstStop = NL;
+        L.xExit[tid] = exitp;
+        L.xFlag[tid] = fl;
+        __syncthreads();
+        if (fl != 0) atomicMin(&L.firstStop, tid);
+        __syncthreads();
+        const int f = L.firstStop;
+        const bool valid = tid <= f;
+        if (f < NL && L.xFlag[f] == 2) return;   // invalid code or out of input: the block does not parse
         unsigned pn = valid ? n : 0u, pu = valid ? u : 0u, pr = valid ? r : 0u, plb = valid ? lb : 0u;
-        unsigned sn = pn, su = pu, sr = pr;   // inclusive scans
+        unsigned sn = pn, su = pu, sr = pr;   // inclusive scans: inside the wave, then across waves
         for (int d = 1; d < 64; d <<= 1) {
             unsigned a = __shfl_up(sn, d), b = __shfl_up(su, d), c2 = __shfl_up(sr, d);
             if (lane >= d) { sn += a; su += b; sr += c2; }
         }
-        int nd = valid && r ? need - (int)(nU + (su - pu)) : -0x40000000;
-        nd = wave_max_i32(nd);
-        if (nd > needHist) needHist = nd;
+        const int plbw = wave_sum_i32((int)plb);
+        if (lane == 63) { L.wsN[wave] = sn; L.wsU[wave] = su; L.wsR[wave] = sr; }
+        if (lane == 0) L.wsB[wave] = (unsigned)plbw;
+        __syncthreads();
+        unsigned offN = 0, offU = 0, offR = 0, totN = 0, totU = 0, totR = 0, totB = 0;
+        for (int w = 0; w < nw; w++) {
+            if (w < wave) { offN += L.wsN[w]; offU += L.wsU[w]; offR += L.wsR[w]; }
+            totN += L.wsN[w]; totU += L.wsU[w]; totR += L.wsR[w]; totB += L.wsB[w];
+        }
+        sn += offN; su += offU; sr += offR;
+        {
+            int nd = valid && r ? need - (int)(nU + (su - pu)) : -0x40000000;
+            nd = wave_max_i32(nd);
+            __syncthreads();
+            if (lane == 0) L.wsM[wave] = nd;
+            __syncthreads();
+            for (int w = 0; w < nw; w++) if (L.wsM[w] > needHist) needHist = L.wsM[w];
+        }
         if (EMIT && valid) {
             int e2, need2, fl2;
             unsigned n2, u2, r2, lb2;
@@ -705,17 +752,21 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
                          fl2);
             if (replay) exitp = e2;
         }
-        if (recording) {   // leave the verified chunks to the emit pass
-            unsigned idx = 0;
-            if (lane == 0) idx = atomicAdd(pool.next, 1u);
-            idx = __shfl(idx, 0);
-            if (idx < pool.cap) {
-                D4GChunkBatch* bt = pool.batches + idx;
+        if (replay) {   // (the replayed exits were not exchanged yet)
+            __syncthreads();
+            L.xExit[tid] = exitp;
+            __syncthreads();
+        }
+        if (recording) {   // leave the verified chunks to the emit pass: nw consecutive records, one per wave
+            __syncthreads();
+            if (tid == 0) L.bc = (long long)atomicAdd(pool.next, (unsigned)nw);
+            __syncthreads();
+            const unsigned idx = (unsigned)L.bc;
+            if (idx + (unsigned)nw <= pool.cap) {
+                D4GChunkBatch* bt = pool.batches + idx + wave;
                 bt->rec[lane] = make_uint4((uint32_t)(baseBits + start - tokensStart), n | (r << 10) | ((unsigned)fl << 20), u, lb);
-                if (lane == 0) {
-                    bt->next = -1;
-                    if (recBatch >= 0) pool.batches[recBatch].next = (int32_t)idx;
-                }
+                if (lane == 0) bt->next = -1;
+                if (tid == 0 && recBatch >= 0) pool.batches[recBatch].next = (int32_t)idx;
                 if (firstBatch < 0) firstBatch = (int)idx;
                 recBatch = (int)idx;
             } else {
@@ -724,17 +775,18 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
             }
         }
         if (replay) recBatch = pool.batches[recBatch].next;
-        nTok += __shfl(sn, 63);
-        nU += __shfl(su, 63);
-        nRef += __shfl(sr, 63);
-        litlenBits += (unsigned)wave_sum_i32((int)plb);
-        if (f < 64) { endBit = baseBits + __shfl(exitp, f); break; }
+        nTok += totN;
+        nU += totU;
+        nRef += totR;
+        litlenBits += totB;
+        if (f < NL) { endBit = baseBits + L.xExit[f]; break; }
         if (replay && recBatch < 0) return;   // (a chain that ends before the block does: cannot happen for a recorded block)
-        s0 = baseBits + __shfl(exitp, 63);
-        G += 64LL * C;
+        s0 = baseBits + L.xExit[NL - 1];
+        G += (long long)NL * C;
+        __syncthreads();   // (xExit / wave sums are rewritten by the next batch)
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         S->litlenBits = (long long)litlenBits;
         S->sizeBits = S->hdrBits + (long long)litlenBits;
         S->valid = 1;
@@ -751,21 +803,21 @@ __device__ __forceinline__ void d4g_parse_block(const D4GStreamDesc& sd, long lo
     po.firstBatch = firstBatch == -2 ? -1 : firstBatch;
     if (EMIT) {
         D4GState* g = out.states + em->stateIdx;
-        for (int i = lane; i < (int)(sizeof(D4GState) / 4); i += 64) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
+        for (int i = tid; i < (int)(sizeof(D4GState) / 4); i += NL) ((uint32_t*)g)[i] = ((uint32_t*)S)[i];
     }
 }
 
 // With `hits` set, only the candidates that parse are reported, compacted (the scan's candidates are mostly
 // false positives; the host reads back a few hundred records instead of all of them).
 struct D4GProbeHit { D4GProbeIn in; D4GProbeOut out; };
-__global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
+__global__ void __launch_bounds__(D4G_PARSE_MAXTHREADS) k_probe_blocks(const D4GStreamDesc* streams, const D4GProbeIn* in, D4GProbeOut* outp, unsigned n,
                                                      D4GProbeHit* hits, unsigned* nHits, D4GChunkPool pool) {
     if (blockIdx.x >= n) return;
     const D4GProbeIn pi = in[blockIdx.x];
     D4GProbeOut po;
     D4GParseOut none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     d4g_parse_block<false>(streams[pi.stream], pi.bitPos, pi.strict, po, nullptr, none, pool);
-    if ((threadIdx.x & 63) == 0) {
+    if (threadIdx.x == 0) {
         if (hits) {
             if (po.status == 0) {
                 unsigned k = atomicAdd(nHits, 1u);
@@ -780,12 +832,12 @@ __global__ void __launch_bounds__(64) k_probe_blocks(const D4GStreamDesc* stream
 
 // Emit: one wave per block decodes it again, now writing tokens, back-reference records, the block's
 // initial state (stored blocks: their bytes).
-__global__ void __launch_bounds__(64) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors,
+__global__ void __launch_bounds__(D4G_PARSE_MAXTHREADS) k_emit_blocks(const D4GStreamDesc* streams, const D4GEmitIn* in, D4GParseOut out, int32_t* errors,
                                                     D4GChunkPool pool) {
     const D4GEmitIn em = in[blockIdx.x];
     D4GProbeOut po;
     d4g_parse_block<true>(streams[em.stream], em.bitPos, 0, po, &em, out, pool);
-    if ((threadIdx.x & 63) == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
+    if (threadIdx.x == 0 && (po.status != 0 || po.uLen != em.uLen)) atomicAdd(errors, 1);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -529,8 +529,6 @@ void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const siz
             i1++;
         }
         try {
-            size_t usedBefore = R.used;
-            (void)usedBefore;
             compress_group(R, i0, i1, raw, len, fromDevice, list, merge);
             i0 = i1;
         } catch (const std::runtime_error& ex) {

@@ -10,6 +10,14 @@
  * d4g_free().  All functions return 0 on success and a negative value on failure (text in
  * d4g_last_error()).  Nothing here has a CPU fallback: without a usable HIP device
  * d4g_init() fails and every other call returns D4G_ERR_NODEVICE.
+ *
+ * SCOPE: mode NONE (parse, candidate search, mergeBlocks, write) and the zlib-family recompress path (JavaCompressor /
+ * JZLibCompressor at level 9, CompressionUtil.compress and CMDUtil's recompress loop for mode CHEAP) are built.  The Zopfli
+ * compressors (CafeUndZopfli, JZopfli) are NOT: modes ZOPFLI and above return D4G_ERR_ARG — never a substitute result.
+ *
+ * THREADS: d4g_init / d4g_shutdown are exclusive.  Everything else may be called from several host threads at once
+ * (CompressionUtil's pool, C/CompressionUtil.java:111-117): every thread gets its own HIP streams; a d4g_batch is used by
+ * one thread at a time.
  */
 #ifndef DEFT4G_H
 #define DEFT4G_H

@@ -116,6 +116,10 @@ inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
 template <typename T>
 inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+template <typename T>
+inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T>
+inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 
 // ---- runtime half (mirrors d4g_rt.h) ----
 #define RT_MAX_LANES 8

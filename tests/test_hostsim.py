@@ -83,6 +83,34 @@ def test_batch_of_synthetic_streams_matches_oracle(sim, monkeypatch, mode):
         b.close()
 
 
+@pytest.mark.parametrize("threads", ["128", "512"])
+def test_block_decoder_with_several_waves(sim, monkeypatch, threads):
+    """The GPU decodes a block with a whole workgroup (512 threads: a batch is 512 chunks of 512 bits, the exits travel
+    between waves through LDS); the emulator's default is one wave.  Here the multi-wave path runs in the emulator:
+    golden pairs, a multi-block stream whose blocks need several batches at 128 threads, stored / fixed / empty blocks."""
+    monkeypatch.setenv("D4G_SIM_PARSE_THREADS", threads)
+    D, L = sim
+    for stem in ("lz-twice-twice.s00", "text.s01", "apng_ball.s09"):
+        p = MAN[stem]
+        a = rd(stem + ".in.deflate")
+        b = D.Batch([a], lib=L).run(p["merge_blocks"])
+        assert b.result(0)["saved_bits"] == p["saved_bits"] and b.output(0) == rd(stem + ".out.deflate")
+        b.close()
+    raw = synth.reptext(120000, 31)
+    c0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    ins = [synth.deflate9(raw), c0.compress(raw[:3000]) + c0.flush(), c1.compress(raw[:9000]) + c1.flush(), synth.deflate9(b""),
+           synth.deflate9(raw, zlib.Z_HUFFMAN_ONLY)]
+    b = D.Batch(ins, lib=L).parse()
+    for i, a in enumerate(ins):
+        assert b.decoded(i) == zlib.decompress(a, -15), i
+    b.close()
+    rc, want, saved, _, _ = O.optimise(ins[0], False)
+    b = D.Batch([ins[0]], lib=L).run(False)
+    assert b.result(0)["saved_bits"] == saved and b.output(0) == want
+    b.close()
+
+
 def test_long_blocks_decode_in_checkpoint_segments(sim):
     """Blocks longer than 1024 tokens are emitted by one wave per checkpoint segment (and blocks beyond 32 Ki
     tokens thin their checkpoint set): tokens, decoded bytes and the merged histogram must still be exact."""
