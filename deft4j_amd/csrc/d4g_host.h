@@ -932,6 +932,11 @@ struct Batch {
                 }
                 unsigned long long ch[JB];
                 rt_d2h(ch, dChanged + base, JB * 8);
+                if (getenv("D4G_DEBUG_JUMP")) {
+                    fprintf(stderr, "jump rounds %d..%d of %lld bytes, moved:", base, base + JB - 1, (long long)totalU);
+                    for (int k = 0; k < JB; k++) fprintf(stderr, " %llu", ch[k]);
+                    fprintf(stderr, "\n");
+                }
                 bool done = false;
                 for (int k = 0; k < JB; k++) {
                     stats.jump_rounds++;                   // round base + k ran (its predecessor moved enough)

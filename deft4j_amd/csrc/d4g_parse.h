@@ -157,17 +157,20 @@ __device__ __forceinline__ uint64_t d4g_peek64(const uint8_t* inbuf, int posRel)
 // Huffman.buildCodes (B/huffman/Huffman.java:35-64) + decoder tables.  Lane 0 prepares the
 // canonical structure, all lanes fill the LUT.
 __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
-    const int lane = threadIdx.x, nl = blockDim.x;   // every thread of the workgroup helps to fill the table
+    const int lane = threadIdx.x, nl = blockDim.x;   // every thread of the workgroup helps
+    __syncthreads();
+    if (lane < 16) { T->count[lane] = 0; T->first[lane] = 0; T->offs[lane] = 0; }
+    __syncthreads();
+    for (int i = lane; i < n; i += nl)
+        if (lens[i] > 0 && lens[i] < 16) atomicAdd(&T->count[lens[i]], 1);
     __syncthreads();
     if (lane == 0) {
-        for (int l = 0; l < 16; l++) { T->count[l] = 0; T->first[l] = 0; T->offs[l] = 0; }
-        int nc = 0;
-        for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) { T->count[lens[i]]++; nc++; }
-        int next = 0, lastShift = 0, o = 0;
+        int nc = 0, next = 0, lastShift = 0, o = 0;
         long long kraft = 0;
         for (int l = 1; l <= 15; l++) {
             T->offs[l] = o;
             o += T->count[l];
+            nc += T->count[l];
             if (T->count[l]) {
                 next <<= (l - lastShift);
                 lastShift = l;
@@ -179,9 +182,16 @@ __device__ void d4g_build_decoder(D4GDecTab* T, const uint8_t* lens, int n) {
         T->useLut = kraft <= (1 << 15);
         T->complete = kraft == (1 << 15);
         T->nCodes = nc;
-        int fill[16];
-        for (int l = 0; l < 16; l++) fill[l] = T->offs[l];
-        for (int i = 0; i < n; i++) if (lens[i] > 0 && lens[i] < 16) T->sorted[fill[lens[i]]++] = (uint16_t)i;
+    }
+    __syncthreads();
+    // symbols ordered by (length, index): symbol i sits after the lower-numbered symbols of its length
+    for (int i = lane; i < n; i += nl) {
+        const int l = lens[i];
+        if (l > 0 && l < 16) {
+            int rank = 0;
+            for (int j = 0; j < i; j++) rank += lens[j] == l;
+            T->sorted[T->offs[l] + rank] = (uint16_t)i;
+        }
     }
     __syncthreads();
     for (int i = lane; i < (1 << D4G_LUT_BITS); i += nl) T->lut[i] = 0xffff;
