@@ -1110,7 +1110,11 @@ struct Batch {
             e1.record();
             std::vector<D4GRoundResult> r(sub.size());
             rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
-            msSearch += rt_elapsed_ms(e0, e1);
+            const float roundMs = rt_elapsed_ms(e0, e1);
+            msSearch += roundMs;
+            if (getenv("D4G_DEBUG_ROUNDS"))
+                fprintf(stderr, "search round %lld (%s program, %s): %d active blocks, %.3f ms\n", (long long)stats.rounds, pass == 0 ? "dynamic" : "fixed",
+                        persist ? "persistent" : "levels", nA, roundMs);
             for (size_t k = 0; k + 1 < evs.size(); k += 2) stats.ms_state_kernels += rt_elapsed_ms(*evs[k], *evs[k + 1]);
             for (size_t k = 0; k < sub.size(); k++) {
                 res[subPos[k]] = r[k];
