@@ -250,3 +250,22 @@ def test_recompress_modes_in_the_emulator(sim):
     assert res[0]["recompress_saved"] > 0
     with pytest.raises(IOError):
         D.CompressionUtil(D.MODE_ZOPFLI, lib=L).compress(b"abc")      # needs a Zopfli compressor: loud failure, no substitute
+
+
+def test_gzip_file_through_mode_cheap_in_the_emulator(sim):
+    """`deft4j optimise --mode=CHEAP` on a small gzip file through the container layer (containers.optimise_files):
+    the weakly compressed member is recompressed and grafted, the trailer recomputed, the transcript carries the
+    reference's recompression lines (M/CMDUtil.java:95,103)."""
+    import gzip
+    import oracle_compose as OC
+    from deft4j_amd import containers
+    D, L = sim
+    text = synth.reptext(2600, 77)
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15)
+    payload = c1.compress(text) + c1.flush()
+    gz = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\x03" + payload + (zlib.crc32(text) & 0xffffffff).to_bytes(4, "little") + len(text).to_bytes(4, "little")
+    (out, lines), = containers.optimise_files([gz], True, lib=L, mode=D.MODE_CHEAP)
+    assert gzip.decompress(out) == text
+    want = OC.recompress(payload, True)
+    assert want["recompress_saved"] > 0 and out[10:-8] == want["out"]
+    assert lines[-1] == "Saved %d bits with recompression" % want["recompress_saved"]
