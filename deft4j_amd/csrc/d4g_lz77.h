@@ -268,19 +268,32 @@ D4G_DEV void lz_search(const LzCtx& c, const LzStream& st, const uint32_t* win, 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_lz_parse: deflate_slow over chunks.  blockDim.x / 64 consecutive chunks of one stream share the staged window.
 // exact = 0: every chunk but a stream's first starts LZ_WARM positions early from a clean state and records from its
-//            first loop top inside the chunk;  exact = 1: the chunk starts from its predecessor's recorded exit state.
+//            first loop top inside the chunk;  exact = 1 (one wave per job): the chunk starts from its predecessor's
+//            recorded exit state and the wave carries on into the following chunks while they disagree.
 // ---------------------------------------------------------------------------------------------------------------------
 #define LZ_PARSE_MAXWAVES 16   // 16 chunks share one staged window: 66 KB of LDS, two workgroups = 32 waves per CU
-__global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, const LzParseJob* jobs, int exact) {
+// `heads` (exact mode): per chunk, 1 = another workgroup re-runs this chunk in the same pass.  A re-run chunk whose new exit
+// state differs from what its successor started from goes straight on into the successor (re-staging the window), and on,
+// until a chunk's recorded entry equals the exit just produced — or the successor is somebody else's job.  Inputs whose
+// speculative parses never fall into step (one long run: every chunk starts a 258-byte match at a different phase) are
+// thus parsed by one wave in one pass instead of one pass per chunk.
+__global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, const LzParseJob* jobs, int exact, const uint8_t* heads) {
     __shared__ uint32_t win[(32768 + LZ_WARM + LZ_PARSE_MAXWAVES * LZ_CHUNK + LZ_WIN_SLACK + 64) / 4];
     const LzParseJob job = jobs[blockIdx.x];
     const LzStream st = c.streams[job.stream];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const long long tile0 = (long long)job.firstChunk * LZ_CHUNK;
+    const uint8_t* wb = (const uint8_t*)win;
+    int tileChunk = job.firstChunk;                 // first chunk of the staged tile
+    unsigned long long carry = 0;                   // exact mode, from the second chunk of a chain on: the state to start from
+    bool chained = false;
+    for (;;) {
+    const long long tile0 = (long long)tileChunk * LZ_CHUNK;
     long long w0 = tile0 - 32768 - LZ_WARM;
     if (w0 < 0) w0 = 0;
     w0 &= ~15LL;
-    long long w1 = tile0 + (long long)nw * LZ_CHUNK + LZ_WIN_SLACK;
+    const int span = exact ? LZ_PARSE_MAXWAVES : nw;   // chunks the staged window serves (exact mode: the one wave walks through them)
+    long long w1 = tile0 + (long long)span * LZ_CHUNK + LZ_WIN_SLACK;
+    __syncthreads();
     {   // stage [w0, w1): the input is padded with zero bytes, so reading past st.len is harmless
         long long lim = ((st.len + 15) & ~15LL) + 320;
         if (w1 > lim) w1 = lim;
@@ -290,21 +303,21 @@ __global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, co
         for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const int chunk = job.firstChunk + wave;
-    if (chunk >= st.nChunks) return;
+    int chunk = tileChunk + wave;
+    for (;;) {                                      // (exact mode: the chunks of the staged span, one after the other)
+    if (chunk >= st.nChunks) return;                // (speculative pass: the tile's last waves may have no chunk; exact mode has one wave)
     const long long c0 = (long long)chunk * LZ_CHUNK;
     long long c1 = c0 + LZ_CHUNK;
     if (c1 > st.len) c1 = st.len;
     LzChunkMeta* M = c.meta + job.metaBase + chunk;
     uint32_t* tokOut = c.chunkTok + (long long)(job.metaBase + chunk) * (LZ_CHUNK + 2);
-    const uint8_t* wb = (const uint8_t*)win;
 
     long long p;
     int ma = 0, ml = 2, md = 0;
     bool rec;
     if (chunk == 0) { p = 0; rec = true; }
     else if (exact) {
-        unsigned long long e = (M - 1)->exit;
+        unsigned long long e = chained ? carry : (M - 1)->exit;
         p = (long long)(e & 0xffffffffULL);
         ml = (int)((e >> 32) & 0x1ff);
         ma = (int)((e >> 41) & 1);
@@ -364,15 +377,28 @@ __global__ void __launch_bounds__(64 * LZ_PARSE_MAXWAVES) k_lz_parse(LzCtx c, co
         p = st.len;
     }
     if (ntok & 63u) { if (lane < (int)(ntok & 63u)) tokOut[(ntok & ~63u) + lane] = tokbuf; }
+    const unsigned long long exitState = lz_pack_state(p, ma, ml, md);
     if (lane == 0) {
         M->entry = entry;
-        M->exit = lz_pack_state(p, ma, ml, md);
+        M->exit = exitState;
         M->ntok = ntok;
         M->nmatch = nmatch;
         M->firstPos = (uint32_t)(firstPos < 0 ? p : firstPos);
         M->pad = lastTok;   // the chunk's last token (the host needs the stream's last one: match or literal)
         M->dcost = dcost;
         M->pad2 = 0;
+    }
+    if (!exact) return;
+    // exact mode (one wave): does the successor have to follow?
+    const int next = chunk + 1;
+    if (next >= st.nChunks || heads[job.metaBase + next]) return;
+    const unsigned long long nextEntry = (M + 1)->entry;      // (the successor is nobody's job in this pass: its meta is stable)
+    if (nextEntry == exitState) return;
+    carry = exitState;
+    chained = true;
+    chunk = next;
+    if (next >= tileChunk + span) { tileChunk = next; break; }   // past the staged window: stage the next one
+    }
     }
 }
 

@@ -133,13 +133,15 @@ struct LzFront {
             }
             LzParseJob* dJobs = (LzParseJob*)rt_malloc(std::max(jobs.size(), (size_t)metaTot) * sizeof(LzParseJob) + 16);
             rt_h2d(dJobs, jobs.data(), jobs.size() * sizeof(LzParseJob));
-            RT_LAUNCH(k_lz_parse, jobs.size(), 64 * LZ_PARSE_MAXWAVES, c, dJobs, 0);
+            RT_LAUNCH(k_lz_parse, jobs.size(), 64 * LZ_PARSE_MAXWAVES, c, dJobs, 0, (const uint8_t*)nullptr);
             B.stats.kernel_launches++;
             B.stats.lz_parse_passes = 1;
-            int32_t* dIdx = (int32_t*)rt_malloc((size_t)metaTot * 4 + 16);
-            int32_t* dRedo = (int32_t*)rt_malloc((size_t)metaTot * 4 + 16);
-            unsigned* dN = (unsigned*)rt_malloc(16);
+            int32_t* dIdx = tmp.own((int32_t*)rt_malloc((size_t)metaTot * 4 + 16));
+            int32_t* dRedo = tmp.own((int32_t*)rt_malloc((size_t)metaTot * 4 + 16));
+            uint8_t* dHeads = tmp.own((uint8_t*)rt_malloc((size_t)metaTot + 16));
+            unsigned* dN = tmp.own((unsigned*)rt_malloc(16));
             rt_h2d(dIdx, chunkIndex.data(), (size_t)metaTot * 4);
+            std::vector<uint8_t> heads((size_t)metaTot);
             for (int pass = 0;; pass++) {
                 if (pass > 100000) throw std::runtime_error("lz77 parse did not converge");
                 rt_memset(dN, 0, 4);
@@ -150,19 +152,29 @@ struct LzFront {
                 if (nr == 0) break;
                 std::vector<int32_t> redo(nr);
                 rt_d2h(redo.data(), dRedo, (size_t)nr * 4);
-                std::vector<LzParseJob> rj(nr);
+                // A run of consecutive disagreeing chunks is one job: its first chunk (the head) is re-run from its
+                // predecessor's exit and the wave carries on through the run — and beyond, while exits keep differing
+                // from recorded entries — until it falls into step or reaches another job's head.
+                std::fill(heads.begin(), heads.end(), 0);
+                std::vector<char> bad((size_t)metaTot, 0);
+                for (unsigned k = 0; k < nr; k++) bad[redo[k]] = 1;
+                std::vector<LzParseJob> rj;
                 for (unsigned k = 0; k < nr; k++) {
-                    const Parse& P = parses[chunkParse[redo[k]]];
-                    rj[k] = {P.input, chunkIndex[redo[k]], (int32_t)P.metaBase, P.strategy};
+                    const int m = redo[k];
+                    if (chunkIndex[m] > 0 && bad[m - 1]) continue;   // inside a run: the run's head gets there
+                    const Parse& P = parses[chunkParse[m]];
+                    rj.push_back({P.input, chunkIndex[m], (int32_t)P.metaBase, P.strategy});
+                    heads[m] = 1;
                 }
-                rt_h2d(dJobs, rj.data(), (size_t)nr * sizeof(LzParseJob));
-                RT_LAUNCH(k_lz_parse, nr, 64, c, dJobs, 1);
+                rt_h2d(dHeads, heads.data(), (size_t)metaTot);
+                rt_h2d(dJobs, rj.data(), rj.size() * sizeof(LzParseJob));
+                RT_LAUNCH(k_lz_parse, rj.size(), 64, c, dJobs, 1, (const uint8_t*)dHeads);
                 B.stats.kernel_launches++;
                 B.stats.lz_parse_passes++;
                 B.stats.lz_chunks_rerun += nr;
             }
             rt_d2h(meta.data(), dMeta, (size_t)metaTot * sizeof(LzChunkMeta));
-            rt_free(dJobs); rt_free(dIdx); rt_free(dRedo); rt_free(dN);
+            rt_free(dJobs);
         }
         e2.record();
         B.check_device_errors();
