@@ -1461,7 +1461,12 @@ __global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const in
     d4g_exec_state_op(&L, c, c.active[bs], opList[orel]);
 }
 
-__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_STATE_WAVES) k_persist_state_ops(D4GCtx c, D4GQueue q) {
+// The persistent executor serves small launches (merge rounds, few-block batches) where a workgroup's own latency is
+// what is waited for, not the occupancy: a 128-VGPR budget removes its spills (merge phase of an 8 MiB stream -9 %).
+#ifndef D4G_PERSIST_WAVES
+#define D4G_PERSIST_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_PERSIST_WAVES) k_persist_state_ops(D4GCtx c, D4GQueue q) {
     __shared__ D4GLds L;
     __shared__ int sTask[3], sOk;
     int cursor = 0;
