@@ -47,7 +47,8 @@ STRATEGY_DEFAULT, STRATEGY_FILTERED, STRATEGY_HUFFMAN_ONLY = 0, 1, 2
 EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4g_batch_run", "d4g_batch_stream_result",
            "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_checksums", "d4g_batch_parse", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
            "d4g_size_bits_fallback", "d4g_inflate", "d4g_free", "d4g_batch_create_encode", "d4g_batch_run_encode", "d4g_deflate_streams",
-           "d4g_compress", "d4g_recompress_streams", "d4g_batch_run_recompress", "d4g_batch_recompress_result"]
+           "d4g_compress", "d4g_recompress_streams", "d4g_batch_run_recompress", "d4g_batch_recompress_result", "d4g_zopfli_streams",
+           "d4g_debug_zopfli_table", "d4g_debug_zopfli_code_lengths"]
 
 
 def load_library(path=None):
@@ -106,6 +107,13 @@ def load_library(path=None):
     L.d4g_deflate_streams.restype = ctypes.c_int
     L.d4g_deflate_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_zopfli_streams.restype = ctypes.c_int
+    L.d4g_zopfli_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_debug_zopfli_table.restype = ctypes.c_int
+    L.d4g_debug_zopfli_table.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.d4g_debug_zopfli_code_lengths.restype = ctypes.c_int
+    L.d4g_debug_zopfli_code_lengths.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
     L.d4g_compress.restype = ctypes.c_int
     L.d4g_compress.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int32)]
@@ -278,6 +286,28 @@ def deflate_streams(inputs, encoder=ENC_JVM, strategy=STRATEGY_DEFAULT, lib=None
     rc = L.d4g_deflate_streams(n, arr, lens, encoder, strategy, out, olen)
     if rc != 0:
         raise RuntimeError("d4g_deflate_streams: " + L.d4g_last_error().decode())
+    res = []
+    for i in range(n):
+        res.append(ctypes.string_at(out[i], olen[i]))
+        L.d4g_free(out[i])
+    return res
+
+
+ZOPFLI_SPLIT_FIRST, ZOPFLI_SPLIT_LAST, ZOPFLI_SPLIT_NONE = 0, 1, 2     # Options.BlockSplitting (CafeUndZopfli) / blocksplitting[last] (jzopfli)
+
+
+def zopfli_streams(inputs, iterations=20, splitting=ZOPFLI_SPLIT_FIRST, max_blocks=15, master_block=8 << 20, lib=None):
+    """MultiCafeUndZopfliCompressor / MultiJZopfliCompressor.compressWithOptions for every input (d4g_zopfli_streams)."""
+    L = lib or _need()
+    n = len(inputs)
+    keep = [bytes(s) for s in inputs]
+    arr = (ctypes.c_char_p * max(1, n))(*keep)
+    lens = (ctypes.c_size_t * max(1, n))(*[len(s) for s in keep])
+    out = (ctypes.c_void_p * max(1, n))()
+    olen = (ctypes.c_size_t * max(1, n))()
+    rc = L.d4g_zopfli_streams(n, arr, lens, iterations, splitting, max_blocks, master_block, out, olen)
+    if rc != 0:
+        raise RuntimeError("d4g_zopfli_streams: " + L.d4g_last_error().decode())
     res = []
     for i in range(n):
         res.append(ctypes.string_at(out[i], olen[i]))

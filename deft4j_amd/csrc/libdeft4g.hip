@@ -4,6 +4,7 @@
 
 #include "d4g_host.h"
 #include "d4g_lz77_host.h"
+#include "d4g_zopfli_host.h"
 
 using namespace d4g;
 
@@ -377,6 +378,131 @@ int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, s
     }
     d4g_batch_destroy(b);
     return rc;
+}
+
+// ---- Zopfli encoder ----
+namespace {
+// host inputs -> one padded device buffer (16-byte aligned starts, 512 zero bytes after each end)
+struct ZfUpload {
+    LzScratch own;
+    std::vector<const uint8_t*> ptr;
+    std::vector<i64> len;
+    ZfUpload(size_t n, const uint8_t* const* raw, const size_t* raw_len) {
+        i64 off = 0;
+        std::vector<i64> at(n);
+        for (size_t i = 0; i < n; i++) { at[i] = off; off += (((i64)raw_len[i] + 15) & ~15LL) + 512; }
+        uint8_t* d = own.own((uint8_t*)rt_malloc((size_t)off + 1024));
+        rt_memset(d, 0, (size_t)off + 1024);
+        for (size_t i = 0; i < n; i++) { rt_h2d(d + at[i], raw[i], raw_len[i]); ptr.push_back(d + at[i]); len.push_back((i64)raw_len[i]); }
+        rt_sync();
+    }
+};
+}  // namespace
+
+int d4g_zopfli_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int iterations, int splitting, int max_blocks,
+                       size_t master_block, uint8_t** out, size_t* out_len) {
+    if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; }
+    if (iterations < 1 || splitting < 0 || splitting > 2 || max_blocks < 0 || master_block > ((size_t)8 << 20)) return fail(D4G_ERR_ARG, "bad zopfli options");
+    D4G_API_LOCK();
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    try {
+        bind_device();
+        ZfUpload up(n, raw, raw_len);
+        ZfFront zf;
+        zf.create(n, up.ptr.data(), up.len.data());
+        std::vector<ZfSpec> specs;
+        for (size_t i = 0; i < n; i++) {
+            if (master_block == 0 && raw_len[i] > ((size_t)8 << 20)) return fail(D4G_ERR_ARG, "inputs above 8 MiB need a master block size");
+            specs.push_back({(int32_t)i, iterations, splitting, max_blocks, (long long)master_block});
+        }
+        zf.encode(specs);
+        for (size_t i = 0; i < n; i++) {
+            const size_t nb = (size_t)((zf.outBits[i] + 7) / 8);
+            out[i] = (uint8_t*)malloc(nb ? nb : 1);
+            if (!out[i]) throw std::runtime_error("out of host memory");
+            rt_d2h(out[i], zf.outWords[i], nb);
+            out_len[i] = nb;
+        }
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        for (size_t i = 0; i < n; i++) { free(out[i]); out[i] = nullptr; out_len[i] = 0; }
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_debug_zopfli_table(const uint8_t* raw, size_t n, size_t end, uint16_t* len16, uint16_t* dist16, uint16_t* sublen) {
+    if (!raw || !len16 || !dist16) return fail(D4G_ERR_ARG, "null argument");
+    D4G_API_LOCK();
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    try {
+        bind_device();
+        const uint8_t* rp[1] = {raw};
+        size_t rl[1] = {n};
+        ZfUpload up(1, rp, rl);
+        ZfFront zf;
+        zf.create(1, up.ptr.data(), up.len.data());
+        if (end == 0 || end > n) end = n;
+        zf.ensure_tails({{0, (i64)end}});
+        const ZfFront::Tail& t = zf.tails.at({0, (i64)end});
+        std::vector<uint32_t> table(n * 8 + 8), best(n + 8), pool(zf.pool.cap);
+        rt_d2h(table.data(), zf.hIn[0].table, n * 32);
+        rt_d2h(best.data(), zf.hIn[0].best, n * 4);
+        rt_d2h(pool.data(), zf.pool.words, (size_t)zf.pool.cap * 4);
+        if ((i64)end > t.start && t.table != zf.hIn[0].table + t.start * 8) {
+            rt_d2h(table.data() + t.start * 8, t.table, (size_t)(end - t.start) * 32);
+            rt_d2h(best.data() + t.start, t.best, (size_t)(end - t.start) * 4);
+        }
+        for (size_t i = 0; i < end; i++) {
+            len16[i] = (uint16_t)(best[i] >> 16);
+            dist16[i] = (uint16_t)(best[i] & 0xffff);
+            if (!sublen) continue;
+            int from = 3;
+            auto fill = [&](uint32_t w) { for (int l = from; l <= (int)(w >> 16); l++) sublen[i * 259 + l] = (uint16_t)(w & 0xffff); from = (int)(w >> 16) + 1; };
+            for (int c = 0; c < 8; c++) {
+                const uint32_t w = table[i * 8 + c];
+                if (!w) break;
+                if (c == 7 && (w & ZF_POOL_LINK)) { for (const uint32_t* q = &pool[w & 0x7fffffffu]; *q; q++) fill(*q); break; }
+                fill(w);
+            }
+        }
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+__global__ void __launch_bounds__(64) k_zf_debug_code_lengths(const uint32_t* freq, int n, int maxbits, uint32_t* out) {
+    __shared__ ZfEvalLds E;
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < ZF_NUM_LL; i += 64) { E.llc[i] = i < n ? freq[i] : 0; E.ll[i] = 0; }
+    LZ_WAVE_SYNC();
+    const int m = zf_sort_leaves(E.llc, n, E.u.pm.big[0].w, E.u.pm.big[0].sym);
+    LZ_WAVE_SYNC();
+    if (lane == 0) {
+        ZfPmRef r = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, m, E.lvl[0]};
+        zf_pm_serial(r, maxbits, E.ll);
+    }
+    LZ_WAVE_SYNC();
+    for (int i = lane; i < n; i += 64) out[i] = E.ll[i];
+}
+
+int d4g_debug_zopfli_code_lengths(const uint32_t* freq, int n, int maxbits, uint32_t* lengths) {
+    if (!freq || !lengths || n < 1 || n > ZF_NUM_LL || maxbits < 1 || maxbits > 15) return fail(D4G_ERR_ARG, "bad argument");
+    D4G_API_LOCK();
+    if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
+    try {
+        bind_device();
+        LzScratch own;
+        uint32_t* dF = own.own((uint32_t*)rt_malloc(n * 4));
+        uint32_t* dO = own.own((uint32_t*)rt_malloc(n * 4));
+        rt_h2d(dF, freq, n * 4);
+        RT_LAUNCH(k_zf_debug_code_lengths, 1, 64, dF, n, maxbits, dO);
+        rt_d2h(lengths, dO, n * 4);
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
 }
 
 void d4g_free(void* p) { free(p); }

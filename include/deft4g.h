@@ -122,6 +122,25 @@ int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_l
  * order JVM{DEFAULT, FILTERED, HUFFMAN_ONLY}, [JZopfli], [CafeUndZopfli], JZlib{DEFAULT, FILTERED, HUFFMAN_ONLY}.
  * Only the zlib-family compressors are built: modes that need a Zopfli compressor fail with D4G_ERR_ARG (no silent
  * substitute).  `iter` (Zopfli iterations) is accepted for signature parity and unused by the built modes. */
+/* ---- Zopfli encoder (the recompress modes ZOPFLI / ZOPFLI_EXTENSIVE / ZOPFLI_VERY_EXTENSIVE) ----
+ * MultiCafeUndZopfliCompressor.compressWithOptions (C/MultiCafeUndZopfliCompressor.java:48-52: CafeUndZopfli, master block
+ * 8 << 20, BlockSplitting FIRST / LAST / NONE, `iter` iterations) and MultiJZopfliCompressor.compressWithOptions
+ * (C/MultiJZopfliCompressor.java:78-85: jzopfli, master block 1000000, blocksplittingmax 15 or 0) for n inputs with one
+ * option set: out[i] is a complete raw deflate stream (release with d4g_free).  splitting: D4G_ZOPFLI_SPLIT_*;
+ * max_blocks: 0 = unlimited; master_block: bytes per independently encoded part (0 = the whole input; at most 8 MiB).
+ * The dependencies themselves are not in the reference tree: the algorithm is the published Zopfli, pinned through
+ * oracle/zopfli_oracle.c to libzopfli 1.0.3 and the reference's own asyoulik-zopfli fixture. */
+#define D4G_ZOPFLI_SPLIT_FIRST 0
+#define D4G_ZOPFLI_SPLIT_LAST 1
+#define D4G_ZOPFLI_SPLIT_NONE 2
+int d4g_zopfli_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int iterations, int splitting, int max_blocks,
+                       size_t master_block, uint8_t** out, size_t* out_len);
+/* Test hooks (tests/ only): the match table of one input as Zopfli's sublen arrays — len16[i], dist16[i] and, when sublen
+ * is not NULL, sublen[i * 259 + l] for l <= len16[i] — for block end `end` (0 = the input's end); and the length-limited
+ * code lengths of one frequency vector (n <= 288, maxbits <= 15). */
+int d4g_debug_zopfli_table(const uint8_t* raw, size_t n, size_t end, uint16_t* len16, uint16_t* dist16, uint16_t* sublen);
+int d4g_debug_zopfli_code_lengths(const uint32_t* freq, int n, int maxbits, uint32_t* lengths);
+
 #define D4G_MODE_NONE 0
 #define D4G_MODE_CHEAP 1
 #define D4G_MODE_ZOPFLI 2

@@ -2,7 +2,7 @@
 # Builds the TEST-ONLY CPU emulation of the HIP kernels (see hipsim.h).  Optional arg: "san" for ASan/UBSan.
 set -e
 cd "$(dirname "$0")"
-FLAGS="-O2 -g"
+FLAGS="-O2 -g -ffp-contract=off"
 OUT=libdeft4g_hostsim.so
 if [ "$1" = "waveheap" ]; then FLAGS="$FLAGS -DD4G_SIM_WAVE_HEAP"; OUT=libdeft4g_hostsim_wh.so; fi  # wave-wide tree builder in the emulator (slow)
 if [ "$1" = "san" ]; then FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined"; OUT=libdeft4g_hostsim_san.so; fi

@@ -1,0 +1,71 @@
+"""Zopfli encoder kernels (d4g_zopfli.h) through the C ABI on the GPU: byte-identical to the committed vectors of the
+in-container proxy libzopfli 1.0.3, to the reference's own asyoulik-zopfli fixture, and to the oracle
+(oracle/zopfli_oracle.c, portable log flavour) for the options deft4j uses that the proxy does not have."""
+import json
+import os
+import zlib
+
+import pytest
+
+import deft4j_amd as D
+import synth
+import zopf_lib as Z
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MAN = json.load(open(os.path.join(G, "zopfli_manifest.json")))["cases"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    D.init(0)
+
+
+def test_proxy_vectors_in_one_batch_per_option_set():
+    """every committed libzopfli vector, grouped by option set so that several inputs share a launch"""
+    groups = {}
+    for c in MAN:
+        groups.setdefault((c["iterations"], c["blocksplitting"], c["blocksplittingmax"]), []).append(c)
+    for (it, bs, mb), cases in groups.items():
+        datas = [open(os.path.join(G, "zopfli_%s.bin" % c["name"]), "rb").read() for c in cases]
+        outs = D.zopfli_streams(datas, it, D.ZOPFLI_SPLIT_FIRST if bs else D.ZOPFLI_SPLIT_NONE, mb, 1000000)
+        for c, d, o in zip(cases, datas, outs):
+            want = open(os.path.join(G, "zopfli_%s.deflate" % c["name"]), "rb").read()
+            assert o == want, c["name"]
+            assert zlib.decompress(o, -15) == d
+
+
+def test_reference_fixture_asyoulik_zopfli():
+    """test/asyoulik/asyoulik-zopfli.txt.gz: its payload is what 5 iterations make of the inflated text"""
+    fix = open(os.path.join(G, "asyoulik_asyoulik-zopfli.s00.in.deflate"), "rb").read()
+    text = zlib.decompress(fix, -15)
+    assert D.zopfli_streams([text], 5, D.ZOPFLI_SPLIT_FIRST, 15, 1000000)[0] == fix
+
+
+@pytest.mark.parametrize("split", [D.ZOPFLI_SPLIT_FIRST, D.ZOPFLI_SPLIT_LAST, D.ZOPFLI_SPLIT_NONE])
+def test_deft4j_option_sets_against_the_oracle(split):
+    """CafeUndZopfli as deft4j calls it (8 MiB master block, FIRST / LAST / NONE, iter 20) and jzopfli's unlimited split"""
+    datas = [synth.reptext(60000, 11), synth.pngidat(50000, 3, 200), bytes(40000), synth.reptext(900, 9), b"", b"a"]
+    outs = D.zopfli_streams(datas, 20, split, 15, 8 << 20)
+    for d, o in zip(datas, outs):
+        assert o == Z.deflate(d, 20, split, 15, 8 << 20, Z.LOG_PORTABLE)
+        assert zlib.decompress(o, -15) == d
+    outs = D.zopfli_streams(datas[:2], 6, split, 0, 8 << 20)
+    for d, o in zip(datas[:2], outs):
+        assert o == Z.deflate(d, 6, split, 0, 8 << 20, Z.LOG_PORTABLE)
+
+
+def test_master_blocks_share_the_window():
+    data = synth.reptext(250000, 21)
+    out = D.zopfli_streams([data], 5, D.ZOPFLI_SPLIT_FIRST, 15, 100000)[0]      # three master blocks
+    assert out == Z.deflate(data, 5, Z.SPLIT_FIRST, 15, 100000, Z.LOG_PORTABLE)
+    assert zlib.decompress(out, -15) == data
+
+
+def test_long_runs_and_block_ends_inside_runs():
+    import random
+    rng = random.Random(77)
+    data = b"".join(bytes([rng.randrange(4)]) * rng.randrange(1, 3000) for _ in range(120))
+    for master in (8 << 20, 30000):
+        out = D.zopfli_streams([data], 8, D.ZOPFLI_SPLIT_FIRST, 15, master)[0]
+        assert out == Z.deflate(data, 8, Z.SPLIT_FIRST, 15, master, Z.LOG_PORTABLE)
