@@ -853,15 +853,16 @@ struct ZfSqJob {
     int32_t iterations;
     int32_t fixedModel;                                      // 1: one run with the fixed tree's costs (ZopfliLZ77OptimalFixed) into buffer 0
 };
-struct ZfSqOut { int32_t bestBuf; uint32_t bestSize; long long bestCost; };
+struct ZfSqOut { int32_t bestBuf; uint32_t bestSize; long long bestCost; long long cyc[6]; };   // cyc: greedy, DP, trace+follow, cost, statistics (device clock ticks)
 struct ZfSqLds {
     ZfEvalLds E;
     float cost[1024];
     uint16_t len[1024];
-    uint32_t ent[64][8];
-    uint16_t bl[64];
-    uint8_t lit[64], flag[64];
-    uint32_t gb[256];
+    double llTab[260];              // per match length: the cost of its length symbol (this iteration's model)
+    double litc[64];                // prepared batch: the literal's cost,
+    double cpDc[64][8];             //   per change point: the cost of its distance symbol,
+    uint8_t cpDb[64][8];            //   its distance extra bits
+    uint8_t lbTab[260];             // per match length: length extra bits (+ the fixed tree's code lengths in the fixed model)
     double llsym[ZF_NUM_LL], dsym[ZF_NUM_D];
     uint32_t f[ZF_NUM_LL + ZF_NUM_D], fbest[ZF_NUM_LL + ZF_NUM_D], flast[ZF_NUM_LL + ZF_NUM_D];
 };
@@ -919,87 +920,144 @@ D4G_DEV double zf_min_cost(const ZfSqLds& S, bool fixedModel) {   // GetCostMode
     return zf_model(S, fixedModel, bestlength, bestdist);
 }
 
-// GetBestLengths: fills job.lengthArray[0 .. blocksize]
+// GetBestLengths: fills job.lengthArray[0 .. blocksize].  Everything a position needs that does not depend on the running
+// cost — its literal's cost, its change points with the distance part of their cost, the long-run shortcut flag — is
+// prepared for 64 positions at a time by all lanes, so the per-position chain is: read cost[j], add, compare, write.
 D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
     const ZfView& v = job.v;
     const int lane = threadIdx.x & 63;
     const long long start = v.start, end = v.end;
-    const double mincost = zf_min_cost(S, fixedModel);
     LZ_WAVE_SYNC();
+    for (int k = 3 + lane; k < 259; k += 64) {
+        const int lsym = d4g_len2sym(k, 0), lb = d4g_lsym_ebits(lsym);
+        S.lbTab[k] = (uint8_t)(fixedModel ? (lsym <= 279 ? 7 : 8) + 5 + lb : lb);
+        S.llTab[k] = fixedModel ? 0.0 : S.llsym[lsym];
+    }
+    const double mincost = zf_min_cost(S, fixedModel);
     for (int k = lane; k < 1024; k += 64) { S.cost[k] = 1e30f; S.len[k] = 0; }
     LZ_WAVE_SYNC();
     if (lane == 0) { S.cost[0] = 0.f; job.lengthArray[0] = 0; }
-    long long bb = start - 64;
-    auto load_batch = [&](long long i) {
-        LZ_WAVE_SYNC();
-        const long long p = i + lane;
-        if (p < end) {
-            const uint32_t* e = zf_entry(v, p);
-            const uint4 a = *(const uint4*)e, b = *(const uint4*)(e + 4);
-            S.ent[lane][0] = a.x; S.ent[lane][1] = a.y; S.ent[lane][2] = a.z; S.ent[lane][3] = a.w;
-            S.ent[lane][4] = b.x; S.ent[lane][5] = b.y; S.ent[lane][6] = b.z; S.ent[lane][7] = b.w;
-            S.bl[lane] = (uint16_t)(zf_best(v, p) >> 16);
-            S.lit[lane] = v.data[p];
-            bool fl = false;
-            if (p > start + ZF_MAXM + 1 && p + ZF_MAXM * 2 + 1 < end)
-                fl = zf_samecap(v.same[p], end, p) > ZF_MAXM * 2 && zf_samecap(v.same[p - ZF_MAXM], end, p - ZF_MAXM) > ZF_MAXM;
-            S.flag[lane] = fl ? 1 : 0;
-        }
-        bb = i;
-        LZ_WAVE_SYNC();
-    };
-    // a position's cost and length are final once it is reached: write the length out and recycle the ring slot
-    auto retire = [&](long long j) {
-        if (j > 0) job.lengthArray[j] = S.len[j & 1023];
-        S.cost[j & 1023] = 1e30f;
-    };
+    LZ_WAVE_SYNC();
+    long long bb = start - 64;      // first position of the prepared batch
+    long long retired = 0;          // indices below this have had their length written out and their ring slot recycled
     long long i = start;
+    // lane L keeps the uniform facts of batch position L in registers: they reach the loop through v_readlane, not the LDS
+    uint32_t rMeta = 0, rCl0 = 0xffffffffu, rCl1 = 0xffffffffu, rCl2 = 0xffffffffu, rCl3 = 0xffffffffu;
+#ifdef D4G_HOSTSIM
+#define ZF_READLANE(v, l) __shfl(v, l)
+#else
+#define ZF_READLANE(v, l) (uint32_t)__builtin_amdgcn_readlane((int)(v), l)
+#endif
     while (i < end) {
-        long long j = i - start;
-        if (i >= bb + 64) load_batch(i);
-        if (S.flag[i - bb]) {
+        for (int pass = 0; pass < 2; pass++) {
+            if (i >= bb + 64) {
+                const long long j = i - start;
+                LZ_WAVE_SYNC();
+                for (long long x = retired + lane; x < j; x += 64) {
+                    if (x > 0) job.lengthArray[x] = S.len[x & 1023];
+                    S.cost[x & 1023] = 1e30f;
+                }
+                retired = j;
+                const long long p = i + lane;
+                rMeta = 0; rCl0 = rCl1 = rCl2 = rCl3 = 0xffffffffu;
+                if (p < end) {
+                    const uint32_t* e = zf_entry(v, p);
+                    const uint4 a = *(const uint4*)e, b = *(const uint4*)(e + 4);
+                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    uint32_t cl[8];
+                    int n = 0;
+                    const bool link = (b.w & ZF_POOL_LINK) != 0;
+                    for (int c = 0; c < 8; c++) {
+                        cl[c] = 0xffff;
+                        if (w[c] && !link) {
+                            const int ds = d4g_dist2sym((int)(w[c] & 0xffff));
+                            cl[c] = w[c] >> 16;
+                            S.cpDb[lane][c] = (uint8_t)d4g_dsym_ebits(ds);
+                            S.cpDc[lane][c] = fixedModel ? 0.0 : S.dsym[ds];
+                            n++;
+                        }
+                    }
+                    if (link) n = 255;
+                    rCl0 = cl[0] | (cl[1] << 16); rCl1 = cl[2] | (cl[3] << 16); rCl2 = cl[4] | (cl[5] << 16); rCl3 = cl[6] | (cl[7] << 16);
+                    S.litc[lane] = zf_model_lit(S, fixedModel, v.data[p]);
+                    bool fl = false;
+                    if (p > start + ZF_MAXM + 1 && p + ZF_MAXM * 2 + 1 < end)
+                        fl = zf_samecap(v.same[p], end, p) > ZF_MAXM * 2 && zf_samecap(v.same[p - ZF_MAXM], end, p - ZF_MAXM) > ZF_MAXM;
+                    rMeta = (zf_best(v, p) >> 16) | ((uint32_t)n << 16) | (fl ? 1u << 24 : 0u);
+                }
+                bb = i;
+                LZ_WAVE_SYNC();
+            }
+            if (pass == 1 || !((ZF_READLANE(rMeta, (int)(i - bb)) >> 24) & 1u)) break;
             // inside a long run of one byte: 258 positions take a 258-byte match at distance 1 without searching
+            const long long j = i - start;
             const double symbolcost = zf_model(S, fixedModel, ZF_MAXM, 1);
-            LZ_WAVE_SYNC();
             float nv[5];
-            for (int r = 0, k = lane; k < ZF_MAXM; k += 64, r++) nv[r] = (float)((double)S.cost[(j + k) & 1023] + symbolcost);
+            for (int r = 0; r < 5; r++) { const int k = lane + 64 * r; nv[r] = k < ZF_MAXM ? (float)((double)S.cost[(j + k) & 1023] + symbolcost) : 0.f; }
             LZ_WAVE_SYNC();
-            for (int r = 0, k = lane; k < ZF_MAXM; k += 64, r++) {
-                S.cost[(j + k + ZF_MAXM) & 1023] = nv[r];
-                S.len[(j + k + ZF_MAXM) & 1023] = ZF_MAXM;
+            for (int r = 0; r < 5; r++) {
+                const int k = lane + 64 * r;
+                if (k < ZF_MAXM) { S.cost[(j + k + ZF_MAXM) & 1023] = nv[r]; S.len[(j + k + ZF_MAXM) & 1023] = ZF_MAXM; }
             }
             LZ_WAVE_SYNC();
-            for (int k = lane; k < ZF_MAXM; k += 64) retire(j + k);
-            LZ_WAVE_SYNC();
             i += ZF_MAXM;
-            j += ZF_MAXM;
-            if (i >= bb + 64) load_batch(i);
         }
+        const long long j = i - start;
         const int bi = (int)(i - bb);
-        const int leng = S.bl[bi];
-        const float cjf = S.cost[j & 1023];
-        const double cj = (double)cjf;
+        const uint32_t meta = ZF_READLANE(rMeta, bi);
+        const int leng = (int)(meta & 0xffff), ncp = (int)((meta >> 16) & 0xff);
+        const double cj = (double)S.cost[j & 1023];
         if (lane == 0) {   // literal
-            const double nc = zf_model_lit(S, fixedModel, S.lit[bi]) + cj;
-            if (nc < (double)S.cost[(j + 1) & 1023]) { S.cost[(j + 1) & 1023] = (float)nc; S.len[(j + 1) & 1023] = 1; }
+            const double nc = S.litc[bi] + cj;
+            const int t = (int)((j + 1) & 1023);
+            if (nc < (double)S.cost[t]) { S.cost[t] = (float)nc; S.len[t] = 1; }
         }
         if (leng >= 3) {
             const int kend = (long long)leng < end - i ? leng : (int)(end - i);
             const double mca = mincost + cj;
-            for (int k = 3 + lane; k <= kend; k += 64) {
-                const int t = (int)((j + k) & 1023);
-                const float c = S.cost[t];
-                if ((double)c <= mca) continue;
-                const double nc = zf_model(S, fixedModel, k, zf_sublen(v, S.ent[bi], k)) + cj;
-                if (nc < (double)c) { S.cost[t] = (float)nc; S.len[t] = (uint16_t)k; }
+            if (ncp != 255) {
+                const uint32_t c0 = ZF_READLANE(rCl0, bi), c1 = ZF_READLANE(rCl1, bi), c2 = ZF_READLANE(rCl2, bi), c3 = ZF_READLANE(rCl3, bi);
+                const int rounds = kend <= 66 ? 1 : 4;
+                float cs[4];
+                double ncs[4];
+                for (int r = 0; r < 4; r++) {
+                    if (r < rounds) {
+                        const int k0 = 3 + lane + 64 * r;
+                        const int k = k0 <= kend ? k0 : 3;
+                        cs[r] = S.cost[(j + k) & 1023];
+                        const int ci = ((int)(c0 & 0xffff) < k) + ((int)(c0 >> 16) < k) + ((int)(c1 & 0xffff) < k) + ((int)(c1 >> 16) < k) +
+                                       ((int)(c2 & 0xffff) < k) + ((int)(c2 >> 16) < k) + ((int)(c3 & 0xffff) < k) + ((int)(c3 >> 16) < k);
+                        const int ib = S.lbTab[k] + S.cpDb[bi][ci];
+                        ncs[r] = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[k]) + S.cpDc[bi][ci]) + cj;
+                    }
+                }
+                for (int r = 0; r < 4; r++) {
+                    if (r < rounds) {
+                        const int k = 3 + lane + 64 * r;
+                        if (k <= kend && !((double)cs[r] <= mca) && ncs[r] < (double)cs[r]) {
+                            const int t = (int)((j + k) & 1023);
+                            S.cost[t] = (float)ncs[r];
+                            S.len[t] = (uint16_t)k;
+                        }
+                    }
+                }
+            } else {
+                for (int k = 3 + lane; k <= kend; k += 64) {
+                    const int t = (int)((j + k) & 1023);
+                    const float c = S.cost[t];
+                    if ((double)c <= mca) continue;
+                    const double nc = zf_model(S, fixedModel, k, zf_sublen(v, zf_entry(v, i), k)) + cj;
+                    if (nc < (double)c) { S.cost[t] = (float)nc; S.len[t] = (uint16_t)k; }
+                }
             }
         }
-        LZ_WAVE_SYNC();
-        if (lane == 0) retire(j);
         i++;
         LZ_WAVE_SYNC();
     }
-    if (lane == 0 && end > start) job.lengthArray[end - start] = S.len[(end - start) & 1023];
+    LZ_WAVE_SYNC();
+    for (long long x = retired + lane; x <= end - start; x += 64)
+        if (x > 0) job.lengthArray[x] = S.len[x & 1023];
+    LZ_WAVE_SYNC();
 }
 
 // TraceBackwards + FollowPath: walk lengthArray back from the end (lane 0, through an LDS window), then look every
@@ -1060,16 +1118,24 @@ __global__ void __launch_bounds__(64) k_zf_squeeze(const ZfSqJob* jobs, ZfSqOut*
     if (job.fixedModel) {
         zf_best_lengths(S, job, true);
         const uint32_t n = zf_trace_follow(S, job, 0);
-        if (lane == 0) outs[blockIdx.x] = {0, n, 0};
+        if (lane == 0) outs[blockIdx.x] = {0, n, 0, {0, 0, 0, 0, 0, 0}};
         return;
     }
+#ifdef D4G_HOSTSIM
+#define ZF_CLOCK() 0LL
+#else
+#define ZF_CLOCK() (long long)wall_clock64()
+#endif
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    long long tc = ZF_CLOCK(), tn;
     // first statistics: the greedy parse
     for (int k = lane; k < NH; k += 64) S.f[k] = 0;
     LZ_WAVE_SYNC();
-    zf_greedy_walk<false>(job.v, S.gb, nullptr, nullptr, nullptr, S.f);
+    zf_greedy_walk<false>(job.v, (uint32_t*)S.E.u.chunk, nullptr, nullptr, nullptr, S.f);
     LZ_WAVE_SYNC();
     if (lane == 0) S.f[256] = 1;
     zf_calc_stats(S);
+    tn = ZF_CLOCK(); cyc[0] += tn - tc; tc = tn;
     for (int k = lane; k < NH; k += 64) S.fbest[k] = 0;
     ZfRan ran = {1, 2};
     int cur = 0, bestBuf = 0, lastrandomstep = -1;
@@ -1077,11 +1143,14 @@ __global__ void __launch_bounds__(64) k_zf_squeeze(const ZfSqJob* jobs, ZfSqOut*
     long long bestcost = 0x7fffffffffffffffLL, lastcost = 0;
     for (int it = 0; it < job.iterations; it++) {
         zf_best_lengths(S, job, false);
+        tn = ZF_CLOCK(); cyc[1] += tn - tc; tc = tn;
         const uint32_t n = zf_trace_follow(S, job, cur);
+        tn = ZF_CLOCK(); cyc[2] += tn - tc; tc = tn;
         if (lane == 0) S.E.llc[256] = 1;
         LZ_WAVE_SYNC();
         const long long cost = 3 + zf_dynamic_lengths(S.E, nullptr);
         LZ_WAVE_SYNC();
+        tn = ZF_CLOCK(); cyc[3] += tn - tc; tc = tn;
         if (cost < bestcost) {
             for (int k = lane; k < NH; k += 64) S.fbest[k] = S.f[k];
             bestBuf = cur; bestSize = n; bestcost = cost;
@@ -1112,8 +1181,9 @@ __global__ void __launch_bounds__(64) k_zf_squeeze(const ZfSqJob* jobs, ZfSqOut*
             lastrandomstep = it;
         }
         lastcost = cost;
+        tn = ZF_CLOCK(); cyc[4] += tn - tc; tc = tn;
     }
-    if (lane == 0) outs[blockIdx.x] = {bestBuf, bestSize, bestcost};
+    if (lane == 0) outs[blockIdx.x] = {bestBuf, bestSize, bestcost, {cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], 0}};
 }
 
 // ---------------------------------------------------------------------------------------------------------------

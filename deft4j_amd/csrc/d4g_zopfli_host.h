@@ -277,6 +277,10 @@ inline void ZfFront::encode(const std::vector<ZfSpec>& specs) {
             std::vector<ZfSqOut> outs(jobs.size());
             rt_d2h(outs.data(), dO, jobs.size() * sizeof(ZfSqOut));
             for (size_t q = 0; q < blocks.size(); q++) { blocks[q].out = outs[q]; blocks[q].buf[outs[q].bestBuf].size = outs[q].bestSize; }
+            if (env_int("D4G_DEBUG_ZOPFLI", 0) > 1)
+                for (size_t q = 0; q < blocks.size() && q < 8; q++)
+                    fprintf(stderr, "[zopfli] block %zu (%lld bytes): ticks greedy %lld, DP %lld, trace+follow %lld, cost %lld, statistics %lld\n", q,
+                            (long long)(blocks[q].end - blocks[q].start), outs[q].cyc[0], outs[q].cyc[1], outs[q].cyc[2], outs[q].cyc[3], outs[q].cyc[4]);
         }
     }
     msSqueeze += now_ms() - t0;

@@ -417,6 +417,9 @@ int d4g_zopfli_streams(size_t n, const uint8_t* const* raw, const size_t* raw_le
             specs.push_back({(int32_t)i, iterations, splitting, max_blocks, (long long)master_block});
         }
         zf.encode(specs);
+        if (env_int("D4G_DEBUG_ZOPFLI", 0))
+            fprintf(stderr, "[zopfli] inputs %zu: table %.1f ms, split %.1f ms, squeeze %.1f ms (%lld blocks, %lld position-iterations), final+emit %.1f ms\n", n,
+                    zf.msTable, zf.msSplit, zf.msSqueeze, (long long)zf.squeezeBlocks, (long long)zf.squeezePositions, zf.msEmit);
         for (size_t i = 0; i < n; i++) {
             const size_t nb = (size_t)((zf.outBits[i] + 7) / 8);
             out[i] = (uint8_t*)malloc(nb ? nb : 1);
@@ -512,13 +515,35 @@ void d4g_free(void* p) { free(p); }
 namespace {
 // compressor list of a recompress mode, in CompressionUtil.getCompressors order (C/CompressionUtil.java:44-78 with the
 // flags CMDUtil.java:44-50 derives from the mode)
+#define D4G_COMP_JZOPFLI 2   // list entries beyond the two zlib flavours: `strategy` is the option set's index
+#define D4G_COMP_CAFE 3
 bool mode_specs(int mode, std::vector<LzSpec>& list, std::string& why) {
     list.clear();
     if (mode < D4G_MODE_CHEAP || mode > D4G_MODE_ZOPFLI_VERY_EXTENSIVE) { why = "mode out of range"; return false; }
-    if (mode >= D4G_MODE_ZOPFLI) { why = "this mode needs a Zopfli compressor (CafeUndZopfli / JZopfli), which is not built; only NONE and CHEAP are"; return false; }
-    for (int enc : {LZ_FLAVOR_ZLIB, LZ_FLAVOR_JZLIB})       // java (JVM) first, jzlib last (:51-75)
-        for (int st : {LZ_DEFAULT, LZ_FILTERED, LZ_HUFFMAN_ONLY}) list.push_back({0, enc, st});
+    const bool extensive = mode >= D4G_MODE_ZOPFLI_EXTENSIVE;      // Strategy.EXTENSIVE (CMDUtil.java:46)
+    for (int st : {LZ_DEFAULT, LZ_FILTERED, LZ_HUFFMAN_ONLY}) list.push_back({0, LZ_FLAVOR_ZLIB, st});       // java (JVM) first (:51-58)
+    if (mode >= D4G_MODE_ZOPFLI_VERY_EXTENSIVE)                                                              // jzopfli (:60-62)
+        for (int o = 0; o < (extensive ? 5 : 1); o++) list.push_back({0, D4G_COMP_JZOPFLI, o});
+    if (mode >= D4G_MODE_ZOPFLI)                                                                             // CafeUndZopfli (:64-66)
+        for (int o = 0; o < (extensive ? 3 : 1); o++) list.push_back({0, D4G_COMP_CAFE, o});
+    for (int st : {LZ_DEFAULT, LZ_FILTERED, LZ_HUFFMAN_ONLY}) list.push_back({0, LZ_FLAVOR_JZLIB, st});      // jzlib last (:68-75)
     return true;
+}
+// the option set of a Zopfli list entry: MultiJZopfliCompressor.getOptions (C/MultiJZopfliCompressor.java:18-60: split15/first,
+// split15/last, split0/first, split0/last, nosplit; libzopfli's 1000000-byte master block) and
+// MultiCafeUndZopfliCompressor.getOptions (C/MultiCafeUndZopfliCompressor.java:19-25,33: FIRST, LAST, NONE; 8 MiB master block)
+ZfSpec zopfli_options(const LzSpec& e, int input, int iter) {
+    ZfSpec z{};
+    z.input = input;
+    z.iterations = iter < 1 ? 1 : iter;
+    if (e.encoder == D4G_COMP_CAFE) {
+        z.splitting = e.strategy; z.maxblocks = 15; z.master = 8LL << 20;
+    } else {
+        static const int split[5] = {ZF_SPLIT_FIRST, ZF_SPLIT_LAST, ZF_SPLIT_FIRST, ZF_SPLIT_LAST, ZF_SPLIT_NONE};
+        static const int maxb[5] = {15, 15, 0, 0, 0};
+        z.splitting = split[e.strategy]; z.maxblocks = maxb[e.strategy]; z.master = 1000000;
+    }
+    return z;
 }
 
 // CompressionUtil.compress for inputs that live in host or device memory.  Inputs are processed in groups sized to the
@@ -532,6 +557,8 @@ struct CompressRun {
     size_t used = 0;
     size_t perInput = 0;
     d4g_stats agg;
+    int iter = 20;
+    double msZopfli = 0;
     int64_t outputsOptimised = 0, outputsPruned = 0;
     CompressRun() { memset(&agg, 0, sizeof(agg)); }
     ~CompressRun() { rt_free(dWin); }
@@ -560,7 +587,11 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     const size_t n = i1 - i0;
     // stage 1: every compressor output that can hold back-references
     std::vector<int> lzIdx, hIdx;   // list positions
-    for (size_t k = 0; k < list.size(); k++) (list[k].strategy == LZ_HUFFMAN_ONLY ? hIdx : lzIdx).push_back((int)k);
+    std::vector<int> zIdx;          // the Zopfli entries
+    for (size_t k = 0; k < list.size(); k++) {
+        if (list[k].encoder >= D4G_COMP_JZOPFLI) zIdx.push_back((int)k);
+        else (list[k].strategy == LZ_HUFFMAN_ONLY ? hIdx : lzIdx).push_back((int)k);
+    }
     std::vector<LzSpec> specs;
     for (size_t i = 0; i < n; i++)
         for (int k : lzIdx) { LzSpec s = list[k]; s.input = (int32_t)i; specs.push_back(s); }
@@ -618,6 +649,35 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
                 for (size_t k = 0; k < hIdx.size(); k++) offer(need[q], hIdx[k], &e2->impl, (int)(q * hIdx.size() + k));
         }
     }
+    // stage 3: the Zopfli compressors' outputs, encoded on the device and parsed + optimised like any other stream
+    std::unique_ptr<d4g_batch> e3;
+    if (!zIdx.empty()) {
+        double tz = now_ms();
+        std::vector<const uint8_t*> dp(n);
+        std::vector<i64> dl(n);
+        for (size_t i = 0; i < n; i++) { dp[i] = e1->impl.dU + e1->lz->rawU[i]; dl[i] = e1->lz->rawLen[i]; }
+        ZfFront zf;
+        zf.create(n, dp.data(), dl.data());
+        std::vector<ZfSpec> zs;
+        for (size_t i = 0; i < n; i++)
+            for (int k : zIdx) zs.push_back(zopfli_options(list[k], (int)i, R.iter));
+        zf.encode(zs);
+        std::vector<const uint8_t*> sp(zs.size());
+        std::vector<size_t> sl(zs.size());
+        for (size_t q = 0; q < zs.size(); q++) { sp[q] = (const uint8_t*)zf.outWords[q]; sl[q] = (size_t)((zf.outBits[q] + 7) / 8); }
+        e3.reset(new d4g_batch());
+        e3->impl.create(zs.size(), sp.data(), sl.data(), true);
+        R.msZopfli += now_ms() - tz;
+        e3->impl.run(merge);
+        add_stats(R.agg, e3->impl.stats);
+        R.outputsOptimised += (int64_t)zs.size();
+        for (size_t i = 0; i < n; i++)
+            for (size_t k = 0; k < zIdx.size(); k++) {
+                const int st = (int)(i * zIdx.size() + k);
+                if (e3->impl.streams[st].status != 0) throw std::runtime_error("zopfli output does not parse");
+                offer(i, zIdx[k], &e3->impl, st);
+            }
+    }
     for (size_t i = 0; i < n; i++) {
         const Best& b = best[i];
         const HStream& w = b.owner->streams[b.stream];
@@ -631,7 +691,8 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     }
     rt_sync();
 }
-void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, bool merge) {
+void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, int iter, bool merge) {
+    R.iter = iter;
     std::vector<LzSpec> list;
     std::string why;
     if (!mode_specs(mode, list, why)) throw std::runtime_error(why);
@@ -678,7 +739,6 @@ extern "C" {
 
 int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int mode, int iter, int merge_blocks, uint8_t** out,
                  size_t* out_len, int32_t* winner) {
-    (void)iter;
     if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; if (winner) winner[i] = -1; }
     D4G_API_LOCK();
@@ -689,7 +749,7 @@ int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int
         std::string why;
         if (!mode_specs(mode, probe, why)) return fail(D4G_ERR_ARG, why);
         CompressRun R;
-        compress_run(R, n, raw, raw_len, false, mode, merge_blocks != 0);
+        compress_run(R, n, raw, raw_len, false, mode, iter, merge_blocks != 0);
         for (size_t i = 0; i < n; i++) {
             out[i] = (uint8_t*)malloc(R.len[i] ? R.len[i] : 1);
             if (!out[i]) throw std::runtime_error("out of host memory");
@@ -705,7 +765,7 @@ int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int
 }
 
 // CMDUtil.optimise's per-stream loop on a batch made by d4g_batch_create (locked by the caller)
-static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
+static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) {
     Batch& A = b->impl;
     const size_t n = A.streams.size();
     double t0 = now_ms();
@@ -722,7 +782,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
     std::vector<size_t> rl(ok.size());
     for (size_t k = 0; k < ok.size(); k++) { rp[k] = A.dU + A.streams[ok[k]].uBase; rl[k] = (size_t)A.streams[ok[k]].nU; }
     CompressRun R;
-    compress_run(R, ok.size(), rp.data(), rl.data(), true, mode, merge);
+    compress_run(R, ok.size(), rp.data(), rl.data(), true, mode, iter, merge);
     double t1 = now_ms();
     // new DeflateStream().parse(recompressed); recompStream.optimise(mergeBlocks) — :85-89
     std::vector<const uint8_t*> wp(ok.size());
@@ -762,7 +822,6 @@ static void run_recompress_locked(d4g_batch* b, int mode, bool merge) {
 }
 
 int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks) {
-    (void)iter;
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b || b->lz) return fail(D4G_ERR_ARG, "not a batch of deflate streams");
@@ -771,7 +830,7 @@ int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks)
         std::vector<LzSpec> probe;
         std::string why;
         if (mode != D4G_MODE_NONE && !mode_specs(mode, probe, why)) return fail(D4G_ERR_ARG, why);
-        run_recompress_locked(b, mode, merge_blocks != 0);
+        run_recompress_locked(b, mode, iter, merge_blocks != 0);
         return D4G_OK;
     } catch (const std::exception& ex) {
         return fail(D4G_ERR_RUNTIME, ex.what());

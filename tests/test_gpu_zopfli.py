@@ -69,3 +69,31 @@ def test_long_runs_and_block_ends_inside_runs():
     for master in (8 << 20, 30000):
         out = D.zopfli_streams([data], 8, D.ZOPFLI_SPLIT_FIRST, 15, master)[0]
         assert out == Z.deflate(data, 8, Z.SPLIT_FIRST, 15, master, Z.LOG_PORTABLE)
+
+
+@pytest.mark.parametrize("mode", [D.MODE_ZOPFLI, D.MODE_ZOPFLI_EXTENSIVE, D.MODE_ZOPFLI_VERY_EXTENSIVE])
+def test_recompress_modes_with_zopfli_against_the_composed_oracles(mode):
+    """CompressionUtil.compress for the modes that add the Zopfli compressors (C/CompressionUtil.java:44-78 list order,
+    strict minimum by parsed bit size :144-168): same bytes and the same winning list index as the oracles composed."""
+    import oracle_compose as OC
+    fix = open(os.path.join(G, "asyoulik_asyoulik-gzip.s00.in.deflate"), "rb").read()
+    text = zlib.decompress(fix, -15)
+    datas = [text[:30000], synth.reptext(20000, 31), synth.pngidat(20000, 3, 200), b""]
+    for merge in (True, False):
+        cu = D.CompressionUtil(mode, 5, merge)
+        outs = cu.compress_many(datas)
+        for d, o, w in zip(datas, outs, cu.last_winner):
+            assert (o, w) == OC.compress(d, merge, mode, 5), (mode, merge, len(d))
+            assert zlib.decompress(o, -15) == d
+
+
+def test_recompress_graft_loop_in_mode_zopfli():
+    """CMDUtil.optimise's recompress-compare-graft loop (M/CMDUtil.java:76-105) with mode ZOPFLI"""
+    import oracle_compose as OC
+    raw = synth.reptext(40000, 77)
+    c1 = zlib.compressobj(1, zlib.DEFLATED, -15)
+    streams = [c1.compress(raw) + c1.flush(), synth.deflate9(raw[:15000]), b"\x07junk"]
+    res = D.recompress_streams(streams, D.MODE_ZOPFLI, True, 5)
+    for a, r in zip(streams, res):
+        assert r == OC.recompress(a, True, D.MODE_ZOPFLI, 5), len(a)
+    assert res[0]["recompress_saved"] > 0

@@ -249,7 +249,49 @@ def test_recompress_modes_in_the_emulator(sim):
             assert r == OC.recompress(a, merge), (len(a), merge)
     assert res[0]["recompress_saved"] > 0
     with pytest.raises(IOError):
-        D.CompressionUtil(D.MODE_ZOPFLI, lib=L).compress(b"abc")      # needs a Zopfli compressor: loud failure, no substitute
+        D.CompressionUtil(7, lib=L).compress(b"abc")                  # no such RecompressMode: loud failure
+
+
+def test_zopfli_encoder_in_the_emulator(sim):
+    """The Zopfli kernels on the CPU emulation against the oracle (portable log flavour): code lengths, the match table
+    with a block end inside the input, whole streams for the three splitting options, and the recompress modes that use
+    them (list order JVM, [JZopfli], CafeUndZopfli, JZlib: C/CompressionUtil.java:44-78)."""
+    import ctypes
+    import random
+    import numpy as np
+    import oracle_compose as OC
+    import zopf_lib as ZF
+    D, L = sim
+    rng = random.Random(5)
+    for n, mb in ((288, 15), (32, 15), (19, 7)):
+        for _ in range(25):
+            f = [0] * n
+            for i in rng.sample(range(n), rng.choice((1, 2, 3, n // 2, n))):
+                f[i] = rng.choice((1, 1, 2, 3, rng.randrange(1, 50), rng.randrange(1, 100000)))
+            out = (ctypes.c_uint32 * n)()
+            assert L.d4g_debug_zopfli_code_lengths((ctypes.c_uint32 * n)(*f), n, mb, out) == 0
+            assert list(out) == ZF.length_limited(f, mb)
+    runs = b"".join(bytes([rng.randrange(3)]) * rng.randrange(1, 300) for _ in range(8))
+    for data, end in ((synth.reptext(1000, 5), 600), (runs, len(runs) // 2)):
+        n, e = len(data), end or len(data)
+        l16, d16 = np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        assert L.d4g_debug_zopfli_table(data, n, end, l16.ctypes.data, d16.ctypes.data, None) == 0
+        ol, od = np.zeros(e, np.uint16), np.zeros(e, np.uint16)
+        ZF.lib().zopf_match_table(data, 0, e, ol.ctypes.data, od.ctypes.data, None)
+        assert np.array_equal(l16[:e], np.where(ol >= 3, ol, 0)) and np.array_equal(d16[:e], np.where(ol >= 3, od, 0))
+    text = zlib.decompress(rd("asyoulik_asyoulik-gzip.s00.in.deflate"), -15)
+    mix = text[:220] + bytes(rng.randrange(256) for _ in range(120)) + bytes(560) + text[3000:3100]
+    for split in (ZF.SPLIT_FIRST, ZF.SPLIT_LAST, ZF.SPLIT_NONE):
+        datas = [mix, b"", b"hello hello hello hello", synth.reptext(500, 9)] if split == ZF.SPLIT_FIRST else [mix]
+        outs = D.zopfli_streams(datas, 3, split, 15, 8 << 20, lib=L)
+        for d, o in zip(datas, outs):
+            assert o == ZF.deflate(d, 3, split, 15, 8 << 20, ZF.LOG_PORTABLE), (len(d), split)
+    assert D.zopfli_streams([mix], 2, ZF.SPLIT_FIRST, 0, 400, lib=L)[0] == ZF.deflate(mix, 2, ZF.SPLIT_FIRST, 0, 400, ZF.LOG_PORTABLE)
+    data = [text[:160], b""]
+    for mode in (D.MODE_ZOPFLI, D.MODE_ZOPFLI_VERY_EXTENSIVE):
+        cu = D.CompressionUtil(mode, 2, True, lib=L)
+        for d, o, w in zip(data, cu.compress_many(data), cu.last_winner):
+            assert (o, w) == OC.compress(d, True, mode, 2), (mode, len(d))
 
 
 def test_gzip_file_through_mode_cheap_in_the_emulator(sim):
