@@ -856,10 +856,7 @@ struct ZfSqJob {
 struct ZfSqOut { int32_t bestBuf; uint32_t bestSize; long long bestCost; long long cyc[6]; };   // cyc: greedy, DP, trace+follow, cost, statistics (device clock ticks)
 struct ZfSqLds {
     ZfEvalLds E;
-    float cost[1024];
-    uint16_t len[1024];
     double llTab[260];              // per match length: the cost of its length symbol (this iteration's model)
-    double litc[64];                // prepared batch: the literal's cost,
     double cpDc[64][8];             //   per change point: the cost of its distance symbol,
     uint8_t cpDb[64][8];            //   its distance extra bits
     uint8_t lbTab[260];             // per match length: length extra bits (+ the fixed tree's code lengths in the fixed model)
@@ -920,13 +917,28 @@ D4G_DEV double zf_min_cost(const ZfSqLds& S, bool fixedModel) {   // GetCostMode
     return zf_model(S, fixedModel, bestlength, bestdist);
 }
 
-// GetBestLengths: fills job.lengthArray[0 .. blocksize].  Everything a position needs that does not depend on the running
-// cost — its literal's cost, its change points with the distance part of their cost, the long-run shortcut flag — is
-// prepared for 64 positions at a time by all lanes, so the per-position chain is: read cost[j], add, compare, write.
+// GetBestLengths: fills job.lengthArray[0 .. blocksize].
+//
+// The costs of the next 640 positions live in registers: lane L, register q holds index B + 64 q + L (B = the 64-aligned
+// base of the window).  The position being expanded reads its own cost with v_readlane, every lane relaxes the targets it
+// owns (the literal's and the match lengths'), and once per 64 positions the finished lengths are written out and the
+// registers shift.  Everything that does not depend on the running cost — the literal's cost, the change points with the
+// distance part of their cost, the long-run flag — is prepared for 64 positions at a time by all lanes.
+D4G_DEV uint32_t zf_rl(uint32_t v, int l) {
+#ifdef D4G_HOSTSIM
+    return __shfl(v, l);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+#endif
+}
+D4G_DEV float zf_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+D4G_DEV uint32_t zf_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+#define ZF_NQ 10
 D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
     const ZfView& v = job.v;
     const int lane = threadIdx.x & 63;
     const long long start = v.start, end = v.end;
+    const int size = (int)(end - start);
     LZ_WAVE_SYNC();
     for (int k = 3 + lane; k < 259; k += 64) {
         const int lsym = d4g_len2sym(k, 0), lb = d4g_lsym_ebits(lsym);
@@ -934,129 +946,142 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
         S.llTab[k] = fixedModel ? 0.0 : S.llsym[lsym];
     }
     const double mincost = zf_min_cost(S, fixedModel);
-    for (int k = lane; k < 1024; k += 64) { S.cost[k] = 1e30f; S.len[k] = 0; }
     LZ_WAVE_SYNC();
-    if (lane == 0) { S.cost[0] = 0.f; job.lengthArray[0] = 0; }
-    LZ_WAVE_SYNC();
-    long long bb = start - 64;      // first position of the prepared batch
-    long long retired = 0;          // indices below this have had their length written out and their ring slot recycled
-    long long i = start;
-    // lane L keeps the uniform facts of batch position L in registers: they reach the loop through v_readlane, not the LDS
-    uint32_t rMeta = 0, rCl0 = 0xffffffffu, rCl1 = 0xffffffffu, rCl2 = 0xffffffffu, rCl3 = 0xffffffffu;
-#ifdef D4G_HOSTSIM
-#define ZF_READLANE(v, l) __shfl(v, l)
-#else
-#define ZF_READLANE(v, l) (uint32_t)__builtin_amdgcn_readlane((int)(v), l)
-#endif
-    while (i < end) {
-        for (int pass = 0; pass < 2; pass++) {
-            if (i >= bb + 64) {
-                const long long j = i - start;
-                LZ_WAVE_SYNC();
-                for (long long x = retired + lane; x < j; x += 64) {
-                    if (x > 0) job.lengthArray[x] = S.len[x & 1023];
-                    S.cost[x & 1023] = 1e30f;
-                }
-                retired = j;
-                const long long p = i + lane;
-                rMeta = 0; rCl0 = rCl1 = rCl2 = rCl3 = 0xffffffffu;
-                if (p < end) {
-                    const uint32_t* e = zf_entry(v, p);
-                    const uint4 a = *(const uint4*)e, b = *(const uint4*)(e + 4);
-                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                    uint32_t cl[8];
-                    int n = 0;
-                    const bool link = (b.w & ZF_POOL_LINK) != 0;
-                    for (int c = 0; c < 8; c++) {
-                        cl[c] = 0xffff;
-                        if (w[c] && !link) {
-                            const int ds = d4g_dist2sym((int)(w[c] & 0xffff));
-                            cl[c] = w[c] >> 16;
-                            S.cpDb[lane][c] = (uint8_t)d4g_dsym_ebits(ds);
-                            S.cpDc[lane][c] = fixedModel ? 0.0 : S.dsym[ds];
-                            n++;
-                        }
+    if (lane == 0) job.lengthArray[0] = 0;
+    float C[ZF_NQ];
+    uint32_t Ln[ZF_NQ];
+#pragma unroll
+    for (int q = 0; q < ZF_NQ; q++) { C[q] = 1e30f; Ln[q] = 0; }
+    if (lane == 0) C[0] = 0.f;
+    int B = 0;                  // index of register 0, lane 0
+    int loaded = -64;           // base the batch registers were prepared for
+    uint32_t rMeta = 0, rCl0 = 0xffffffffu, rCl1 = 0xffffffffu, rCl2 = 0xffffffffu, rCl3 = 0xffffffffu, rLitLo = 0, rLitHi = 0;
+    bool afterShortcut = false;
+    int j = 0;
+    while (j < size) {
+        while (j >= B + 64) {   // the window moves on: 64 lengths are final
+            const int x = B + lane;
+            if (x > 0 && x <= size) job.lengthArray[x] = (uint16_t)Ln[0];
+#pragma unroll
+            for (int q = 0; q + 1 < ZF_NQ; q++) { C[q] = C[q + 1]; Ln[q] = Ln[q + 1]; }
+            C[ZF_NQ - 1] = 1e30f; Ln[ZF_NQ - 1] = 0;
+            B += 64;
+        }
+        if (loaded != B) {
+            LZ_WAVE_SYNC();
+            const long long p = start + B + lane;
+            rMeta = 0; rCl0 = rCl1 = rCl2 = rCl3 = 0xffffffffu; rLitLo = rLitHi = 0;
+            if (p < end) {
+                const uint32_t* e = zf_entry(v, p);
+                const uint4 a = *(const uint4*)e, b = *(const uint4*)(e + 4);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                uint32_t cl[8];
+                int n = 0;
+                const bool link = (b.w & ZF_POOL_LINK) != 0;
+                for (int c = 0; c < 8; c++) {
+                    cl[c] = 0xffff;
+                    if (w[c] && !link) {
+                        const int ds = d4g_dist2sym((int)(w[c] & 0xffff));
+                        cl[c] = w[c] >> 16;
+                        S.cpDb[lane][c] = (uint8_t)d4g_dsym_ebits(ds);
+                        S.cpDc[lane][c] = fixedModel ? 0.0 : S.dsym[ds];
+                        n++;
                     }
-                    if (link) n = 255;
-                    rCl0 = cl[0] | (cl[1] << 16); rCl1 = cl[2] | (cl[3] << 16); rCl2 = cl[4] | (cl[5] << 16); rCl3 = cl[6] | (cl[7] << 16);
-                    S.litc[lane] = zf_model_lit(S, fixedModel, v.data[p]);
-                    bool fl = false;
-                    if (p > start + ZF_MAXM + 1 && p + ZF_MAXM * 2 + 1 < end)
-                        fl = zf_samecap(v.same[p], end, p) > ZF_MAXM * 2 && zf_samecap(v.same[p - ZF_MAXM], end, p - ZF_MAXM) > ZF_MAXM;
-                    rMeta = (zf_best(v, p) >> 16) | ((uint32_t)n << 16) | (fl ? 1u << 24 : 0u);
                 }
-                bb = i;
-                LZ_WAVE_SYNC();
+                if (link) n = 255;
+                rCl0 = cl[0] | (cl[1] << 16); rCl1 = cl[2] | (cl[3] << 16); rCl2 = cl[4] | (cl[5] << 16); rCl3 = cl[6] | (cl[7] << 16);
+                const unsigned long long lu = zf_d2u(zf_model_lit(S, fixedModel, v.data[p]));
+                rLitLo = (uint32_t)lu; rLitHi = (uint32_t)(lu >> 32);
+                bool fl = false;
+                if (p > start + ZF_MAXM + 1 && p + ZF_MAXM * 2 + 1 < end)
+                    fl = zf_samecap(v.same[p], end, p) > ZF_MAXM * 2 && zf_samecap(v.same[p - ZF_MAXM], end, p - ZF_MAXM) > ZF_MAXM;
+                rMeta = (zf_best(v, p) >> 16) | ((uint32_t)n << 16) | (fl ? 1u << 24 : 0u);
             }
-            if (pass == 1 || !((ZF_READLANE(rMeta, (int)(i - bb)) >> 24) & 1u)) break;
-            // inside a long run of one byte: 258 positions take a 258-byte match at distance 1 without searching
-            const long long j = i - start;
+            loaded = B;
+            LZ_WAVE_SYNC();
+        }
+        const int o = j - B;
+        const uint32_t meta = zf_rl(rMeta, o);
+        if (((meta >> 24) & 1u) && !afterShortcut) {
+            // inside a long run of one byte: 258 positions take a 258-byte match at distance 1 without searching.
+            // index t = s + 258 takes cost[s] + c for the 258 sources s = j .. j + 257: (q, L) <- (q - 4, L - 2) or (q - 5, L + 62)
             const double symbolcost = zf_model(S, fixedModel, ZF_MAXM, 1);
-            float nv[5];
-            for (int r = 0; r < 5; r++) { const int k = lane + 64 * r; nv[r] = k < ZF_MAXM ? (float)((double)S.cost[(j + k) & 1023] + symbolcost) : 0.f; }
-            LZ_WAVE_SYNC();
-            for (int r = 0; r < 5; r++) {
-                const int k = lane + 64 * r;
-                if (k < ZF_MAXM) { S.cost[(j + k + ZF_MAXM) & 1023] = nv[r]; S.len[(j + k + ZF_MAXM) & 1023] = ZF_MAXM; }
+#pragma unroll
+            for (int q = ZF_NQ - 1; q >= 4; q--) {
+                const int srel = 64 * q + lane - ZF_MAXM;       // the source's index relative to B
+                const float a = __shfl(C[q - 4], (lane + 62) & 63);
+                const float b = q >= 5 ? __shfl(C[q - 5], (lane + 62) & 63) : 0.f;
+                const float src = lane >= 2 ? a : b;
+                if (srel >= o && srel < o + ZF_MAXM) { C[q] = (float)((double)src + symbolcost); Ln[q] = ZF_MAXM; }
             }
-            LZ_WAVE_SYNC();
-            i += ZF_MAXM;
+            j += ZF_MAXM;
+            afterShortcut = true;
+            continue;
         }
-        const long long j = i - start;
-        const int bi = (int)(i - bb);
-        const uint32_t meta = ZF_READLANE(rMeta, bi);
+        afterShortcut = false;
         const int leng = (int)(meta & 0xffff), ncp = (int)((meta >> 16) & 0xff);
-        const double cj = (double)S.cost[j & 1023];
-        if (lane == 0) {   // literal
-            const double nc = S.litc[bi] + cj;
-            const int t = (int)((j + 1) & 1023);
-            if (nc < (double)S.cost[t]) { S.cost[t] = (float)nc; S.len[t] = 1; }
+        const double cj = (double)zf_u2f(zf_rl(zf_f2u(C[0]), o));
+        const double ncLit = zf_u2d((unsigned long long)zf_rl(rLitLo, o) | ((unsigned long long)zf_rl(rLitHi, o) << 32)) + cj;
+        const int kend = leng >= 3 ? (leng < size - j ? leng : size - j) : 0;
+        const double mca = mincost + cj;
+        {   // the literal: index o + 1 sits in register 0, or in register 1 when o == 63
+            const double c0d = (double)C[0], c1d = (double)C[1];
+            if (lane == o + 1 && ncLit < c0d) { C[0] = (float)ncLit; Ln[0] = 1; }
+            if (lane == o - 63 && ncLit < c1d) { C[1] = (float)ncLit; Ln[1] = 1; }
         }
-        if (leng >= 3) {
-            const int kend = (long long)leng < end - i ? leng : (int)(end - i);
-            const double mca = mincost + cj;
-            if (ncp != 255) {
-                const uint32_t c0 = ZF_READLANE(rCl0, bi), c1 = ZF_READLANE(rCl1, bi), c2 = ZF_READLANE(rCl2, bi), c3 = ZF_READLANE(rCl3, bi);
-                const int rounds = kend <= 66 ? 1 : 4;
-                float cs[4];
-                double ncs[4];
-                for (int r = 0; r < 4; r++) {
-                    if (r < rounds) {
-                        const int k0 = 3 + lane + 64 * r;
-                        const int k = k0 <= kend ? k0 : 3;
-                        cs[r] = S.cost[(j + k) & 1023];
-                        const int ci = ((int)(c0 & 0xffff) < k) + ((int)(c0 >> 16) < k) + ((int)(c1 & 0xffff) < k) + ((int)(c1 >> 16) < k) +
-                                       ((int)(c2 & 0xffff) < k) + ((int)(c2 >> 16) < k) + ((int)(c3 & 0xffff) < k) + ((int)(c3 >> 16) < k);
-                        const int ib = S.lbTab[k] + S.cpDb[bi][ci];
-                        ncs[r] = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[k]) + S.cpDc[bi][ci]) + cj;
-                    }
-                }
-                for (int r = 0; r < 4; r++) {
-                    if (r < rounds) {
-                        const int k = 3 + lane + 64 * r;
-                        if (k <= kend && !((double)cs[r] <= mca) && ncs[r] < (double)cs[r]) {
-                            const int t = (int)((j + k) & 1023);
-                            S.cost[t] = (float)ncs[r];
-                            S.len[t] = (uint16_t)k;
-                        }
+        if (kend >= 3) {
+            if (__builtin_expect(ncp != 255 && o + kend < 128, 1)) {
+                // the usual case: at most eight change points, targets within registers 0 and 1
+                const uint32_t c0 = zf_rl(rCl0, o), c1 = zf_rl(rCl1, o), c2 = zf_rl(rCl2, o), c3 = zf_rl(rCl3, o);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (q == 0 || o + kend >= 64) {
+                        const int k = 64 * q + lane - o;
+                        const bool isM = k >= 3 && k <= kend;
+                        const int kk = isM ? k : 3;
+                        const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
+                                       ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                        const int ib = S.lbTab[kk] + S.cpDb[o][ci];
+                        const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
+                        const double cq = (double)C[q];
+                        if (isM && !(cq <= mca) && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
                     }
                 }
             } else {
-                for (int k = 3 + lane; k <= kend; k += 64) {
-                    const int t = (int)((j + k) & 1023);
-                    const float c = S.cost[t];
-                    if ((double)c <= mca) continue;
-                    const double nc = zf_model(S, fixedModel, k, zf_sublen(v, zf_entry(v, i), k)) + cj;
-                    if (nc < (double)c) { S.cost[t] = (float)nc; S.len[t] = (uint16_t)k; }
+                const int qmax = (o + kend) >> 6;
+                uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu, c3 = 0xffffffffu;
+                if (ncp != 255) { c0 = zf_rl(rCl0, o); c1 = zf_rl(rCl1, o); c2 = zf_rl(rCl2, o); c3 = zf_rl(rCl3, o); }
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    if (q <= qmax) {
+                        const int k = 64 * q + lane - o;
+                        const bool isM = k >= 3 && k <= kend;
+                        const int kk = isM ? k : 3;
+                        double nc;
+                        if (ncp != 255) {
+                            const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
+                                           ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                            const int ib = S.lbTab[kk] + S.cpDb[o][ci];
+                            nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
+                        } else {
+                            nc = isM ? zf_model(S, fixedModel, kk, zf_sublen(v, zf_entry(v, start + j), kk)) + cj : 0.0;
+                        }
+                        const double cq = (double)C[q];
+                        if (isM && !(cq <= mca) && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
+                    }
                 }
             }
         }
-        i++;
-        LZ_WAVE_SYNC();
+        j++;
     }
-    LZ_WAVE_SYNC();
-    for (long long x = retired + lane; x <= end - start; x += 64)
-        if (x > 0) job.lengthArray[x] = S.len[x & 1023];
+    // the lengths still in registers
+    while (B <= size) {
+        const int x = B + lane;
+        if (x > 0 && x <= size) job.lengthArray[x] = (uint16_t)Ln[0];
+#pragma unroll
+        for (int q = 0; q + 1 < ZF_NQ; q++) { C[q] = C[q + 1]; Ln[q] = Ln[q + 1]; }
+        B += 64;
+    }
     LZ_WAVE_SYNC();
 }
 
@@ -1092,9 +1117,9 @@ D4G_DEV uint32_t zf_trace_follow(ZfSqLds& S, const ZfSqJob& job, int buf) {
     for (int i = lane; i < ZF_NUM_LL; i += 64) S.E.llc[i] = 0;
     if (lane < ZF_NUM_D) S.E.dc[lane] = 0;
     LZ_WAVE_SYNC();
-    uint16_t* oLit = job.lit[buf];
-    uint16_t* oDist = job.dist[buf];
-    uint32_t* oPos = job.pos[buf];
+    uint16_t* oLit = buf ? job.lit[1] : job.lit[0];       // (no dynamic indexing: it would pin the whole job struct in scratch memory)
+    uint16_t* oDist = buf ? job.dist[1] : job.dist[0];
+    uint32_t* oPos = buf ? job.pos[1] : job.pos[0];
     for (uint32_t f = lane; f < npath; f += 64) {
         const uint32_t w = job.path[cap - npath + f];
         const long long p = v.start + (w >> 9);
@@ -1110,9 +1135,9 @@ D4G_DEV uint32_t zf_trace_follow(ZfSqLds& S, const ZfSqJob& job, int buf) {
     return npath;
 }
 
-__global__ void __launch_bounds__(64) k_zf_squeeze(const ZfSqJob* jobs, ZfSqOut* outs) {
+__global__ void __launch_bounds__(64) k_zf_squeeze(const ZfSqJob* __restrict__ jobs, ZfSqOut* __restrict__ outs) {
     __shared__ ZfSqLds S;
-    const ZfSqJob job = jobs[blockIdx.x];
+    const ZfSqJob& job = jobs[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int NH = ZF_NUM_LL + ZF_NUM_D;
     if (job.fixedModel) {
