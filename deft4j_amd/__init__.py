@@ -34,7 +34,9 @@ class d4g_stats(ctypes.Structure):
                 ("lz_parse_passes", ctypes.c_int64), ("lz_chunks_rerun", ctypes.c_int64), ("lz_symbols", ctypes.c_int64),
                 ("ms_recompress_encode", ctypes.c_double), ("ms_recompress_encode_front", ctypes.c_double),
                 ("ms_recompress_encode_search", ctypes.c_double), ("ms_recompress_reoptimise", ctypes.c_double),
-                ("recompress_outputs", ctypes.c_int64), ("recompress_outputs_pruned", ctypes.c_int64)]
+                ("recompress_outputs", ctypes.c_int64), ("recompress_outputs_pruned", ctypes.c_int64),
+                ("ms_zopfli_table", ctypes.c_double), ("ms_zopfli_split", ctypes.c_double), ("ms_zopfli_squeeze", ctypes.c_double),
+                ("ms_zopfli_emit", ctypes.c_double), ("zopfli_blocks", ctypes.c_int64), ("zopfli_position_iterations", ctypes.c_int64)]
 
 
 class d4g_encoder_spec(ctypes.Structure):

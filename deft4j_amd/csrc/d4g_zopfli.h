@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(ZF_MATCH_THREADS) k_zf_match(const ZfInput* in
                 }
                 const unsigned long long M1 = __ballot(m1), M2 = __ballot(m2);
                 if ((mode == 1 ? M1 : M2) == 0ull) continue;               // the switch to the second chain is only tested at first-chain nodes
-                const int len = (m2 || (mode == 1 && m1)) ? zf_match_len(in.data, p, q, limit) : 0;
+                // lz77.c's quick reject: a candidate that differs at offset `bestlength` cannot set a record, and only records matter
+                int len = 0;
+                if ((m2 || (mode == 1 && m1)) && in.data[q + best] == in.data[p + best]) len = zf_match_len(in.data, p, q, limit);
                 int from = 0;
                 while (!done) {
                     unsigned long long memb = (mode == 1 ? M1 : M2);
@@ -1037,14 +1039,16 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 for (int q = 0; q < 2; q++) {
                     if (q == 0 || o + kend >= 64) {
                         const int k = 64 * q + lane - o;
-                        const bool isM = k >= 3 && k <= kend;
-                        const int kk = isM ? k : 3;
-                        const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
-                                       ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
-                        const int ib = S.lbTab[kk] + S.cpDb[o][ci];
-                        const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
                         const double cq = (double)C[q];
-                        if (isM && !(cq <= mca) && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
+                        const bool isM = k >= 3 && k <= kend && !(cq <= mca);      // (targets already at the model's minimum are skipped, as published)
+                        if (__ballot(isM) != 0ull) {
+                            const int kk = isM ? k : 3;
+                            const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
+                                           ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                            const int ib = S.lbTab[kk] + S.cpDb[o][ci];
+                            const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
+                            if (isM && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
+                        }
                     }
                 }
             } else {
@@ -1055,7 +1059,9 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 for (int q = 0; q < 6; q++) {
                     if (q <= qmax) {
                         const int k = 64 * q + lane - o;
-                        const bool isM = k >= 3 && k <= kend;
+                        const double cq = (double)C[q];
+                        const bool isM = k >= 3 && k <= kend && !(cq <= mca);
+                        if (__ballot(isM) == 0ull) continue;
                         const int kk = isM ? k : 3;
                         double nc;
                         if (ncp != 255) {
@@ -1066,8 +1072,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                         } else {
                             nc = isM ? zf_model(S, fixedModel, kk, zf_sublen(v, zf_entry(v, start + j), kk)) + cj : 0.0;
                         }
-                        const double cq = (double)C[q];
-                        if (isM && !(cq <= mca) && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
+                        if (isM && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
                     }
                 }
             }

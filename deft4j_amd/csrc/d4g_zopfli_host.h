@@ -12,6 +12,7 @@
 //   D           stored / fixed / dynamic cost per final block; fixed-tree re-parse where Zopfli tries it; bit layout; emit
 // The result of every output is a complete raw deflate stream in device memory.
 #pragma once
+#include <tuple>
 #include "d4g_lz77_host.h"
 #include "d4g_zopfli.h"
 
@@ -257,15 +258,26 @@ inline void ZfFront::encode(const std::vector<ZfSpec>& specs) {
         std::vector<std::pair<int, i64>> ends;
         for (Block& b : blocks) ends.push_back({specs[mbs[b.mb].spec].input, b.end});
         ensure_tails(ends);
+        // identical squeezes (same bytes, same iteration count: e.g. LAST and NONE of one master block) run once
+        std::map<std::tuple<int, i64, i64, int>, size_t> first;
+        std::vector<size_t> rep(blocks.size()), jobOf(blocks.size(), (size_t)-1);
         std::vector<ZfSqJob> jobs;
-        for (Block& b : blocks) {
+        for (size_t q = 0; q < blocks.size(); q++) {
+            Block& b = blocks[q];
+            const int input = specs[mbs[b.mb].spec].input, iters = specs[mbs[b.mb].spec].iterations;
+            auto key = std::make_tuple(input, b.start, b.end, iters);
+            auto it = first.find(key);
+            if (it != first.end()) { rep[q] = it->second; continue; }
+            first[key] = q;
+            rep[q] = q;
             const size_t cap = (size_t)(b.end - b.start);
             b.buf[0] = alloc_store(cap); b.buf[1] = alloc_store(cap);
             b.la = dalloc<uint16_t>(cap + 8); b.path = dalloc<uint32_t>(cap + 8);
             ZfSqJob j{};
-            j.v = view(specs[mbs[b.mb].spec].input, b.start, b.end);
+            j.v = view(input, b.start, b.end);
             for (int x = 0; x < 2; x++) { j.lit[x] = b.buf[x].lit; j.dist[x] = b.buf[x].dist; j.pos[x] = b.buf[x].pos; }
-            j.lengthArray = b.la; j.path = b.path; j.iterations = specs[mbs[b.mb].spec].iterations; j.fixedModel = 0;
+            j.lengthArray = b.la; j.path = b.path; j.iterations = iters; j.fixedModel = 0;
+            jobOf[q] = jobs.size();
             jobs.push_back(j);
             squeezeBlocks++;
             squeezePositions += (b.end - b.start) * j.iterations;
@@ -276,11 +288,18 @@ inline void ZfFront::encode(const std::vector<ZfSpec>& specs) {
             RT_LAUNCH(k_zf_squeeze, jobs.size(), 64, dJ, dO);
             std::vector<ZfSqOut> outs(jobs.size());
             rt_d2h(outs.data(), dO, jobs.size() * sizeof(ZfSqOut));
-            for (size_t q = 0; q < blocks.size(); q++) { blocks[q].out = outs[q]; blocks[q].buf[outs[q].bestBuf].size = outs[q].bestSize; }
+            for (size_t q = 0; q < blocks.size(); q++) {
+                if (rep[q] != q) continue;
+                const ZfSqOut& o = outs[jobOf[q]];
+                blocks[q].out = o;
+                blocks[q].buf[o.bestBuf].size = o.bestSize;
+            }
+            for (size_t q = 0; q < blocks.size(); q++)
+                if (rep[q] != q) { blocks[q].out = blocks[rep[q]].out; blocks[q].buf[0] = blocks[rep[q]].buf[0]; blocks[q].buf[1] = blocks[rep[q]].buf[1]; }
             if (env_int("D4G_DEBUG_ZOPFLI", 0) > 1)
-                for (size_t q = 0; q < blocks.size() && q < 8; q++)
-                    fprintf(stderr, "[zopfli] block %zu (%lld bytes): ticks greedy %lld, DP %lld, trace+follow %lld, cost %lld, statistics %lld\n", q,
-                            (long long)(blocks[q].end - blocks[q].start), outs[q].cyc[0], outs[q].cyc[1], outs[q].cyc[2], outs[q].cyc[3], outs[q].cyc[4]);
+                for (size_t q = 0; q < jobs.size() && q < 8; q++)
+                    fprintf(stderr, "[zopfli] squeeze job %zu (%lld bytes): ticks greedy %lld, DP %lld, trace+follow %lld, cost %lld, statistics %lld\n", q,
+                            (long long)(jobs[q].v.end - jobs[q].v.start), outs[q].cyc[0], outs[q].cyc[1], outs[q].cyc[2], outs[q].cyc[3], outs[q].cyc[4]);
         }
     }
     msSqueeze += now_ms() - t0;

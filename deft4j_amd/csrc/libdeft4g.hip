@@ -558,7 +558,8 @@ struct CompressRun {
     size_t perInput = 0;
     d4g_stats agg;
     int iter = 20;
-    double msZopfli = 0;
+    double msZopfli = 0, msZfTable = 0, msZfSplit = 0, msZfSqueeze = 0, msZfEmit = 0;
+    int64_t zfBlocks = 0, zfPosIter = 0;
     int64_t outputsOptimised = 0, outputsPruned = 0;
     CompressRun() { memset(&agg, 0, sizeof(agg)); }
     ~CompressRun() { rt_free(dWin); }
@@ -662,6 +663,8 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
         for (size_t i = 0; i < n; i++)
             for (int k : zIdx) zs.push_back(zopfli_options(list[k], (int)i, R.iter));
         zf.encode(zs);
+        R.msZfTable += zf.msTable; R.msZfSplit += zf.msSplit; R.msZfSqueeze += zf.msSqueeze; R.msZfEmit += zf.msEmit;
+        R.zfBlocks += zf.squeezeBlocks; R.zfPosIter += zf.squeezePositions;
         std::vector<const uint8_t*> sp(zs.size());
         std::vector<size_t> sl(zs.size());
         for (size_t q = 0; q < zs.size(); q++) { sp[q] = (const uint8_t*)zf.outWords[q]; sl[q] = (size_t)((zf.outBits[q] + 7) / 8); }
@@ -811,6 +814,8 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     A.stats.ms_recompress_reoptimise = now_ms() - t1;
     A.stats.recompress_outputs = R.outputsOptimised;
     A.stats.recompress_outputs_pruned = R.outputsPruned;
+    A.stats.ms_zopfli_table = R.msZfTable; A.stats.ms_zopfli_split = R.msZfSplit; A.stats.ms_zopfli_squeeze = R.msZfSqueeze; A.stats.ms_zopfli_emit = R.msZfEmit;
+    A.stats.zopfli_blocks = R.zfBlocks; A.stats.zopfli_position_iterations = R.zfPosIter;
     const d4g_stats* chained[2] = {&es, &b->reopt->stats};
     for (const d4g_stats* o : chained) {   // the same kernels ran in the chained batches: one set of counters
         A.stats.ms_state_kernels += o->ms_state_kernels; A.stats.state_launches += o->state_launches;

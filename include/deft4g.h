@@ -62,6 +62,10 @@ typedef struct d4g_stats {
     double ms_recompress_encode, ms_recompress_encode_front, ms_recompress_encode_search, ms_recompress_reoptimise;
     int64_t recompress_outputs;         /* compressor outputs that went through the candidate search */
     int64_t recompress_outputs_pruned;  /* HUFFMAN_ONLY outputs whose entropy bound already lost: not searched */
+    /* Zopfli compressors (modes ZOPFLI*): wall clock of the match tables, the block-split searches, the squeeze kernel
+     * and the block choice + emission; squeeze work = sum over blocks of iterations x block bytes */
+    double ms_zopfli_table, ms_zopfli_split, ms_zopfli_squeeze, ms_zopfli_emit;
+    int64_t zopfli_blocks, zopfli_position_iterations;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

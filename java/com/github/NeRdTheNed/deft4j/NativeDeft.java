@@ -39,6 +39,9 @@ public final class NativeDeft {
     /** SingleCompressor.compressSingle for every buffer */
     public static native byte[][] deflateStreams(byte[][] raw, int encoder, int strategy) throws java.io.IOException;
 
+    /** MultiCafeUndZopfliCompressor / MultiJZopfliCompressor.compressWithOptions for every buffer (splitting: 0 FIRST, 1 LAST, 2 NONE) */
+    public static native byte[][] zopfliStreams(byte[][] raw, int iterations, int splitting, int maxBlocks, long masterBlock) throws java.io.IOException;
+
     /** CompressionUtil.compress(uncompressedData, threaded) for every buffer */
     public static native byte[][] compress(byte[][] raw, int mode, int iter, boolean mergeBlocks) throws java.io.IOException;
 

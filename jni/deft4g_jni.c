@@ -123,6 +123,23 @@ JNIEXPORT jobjectArray JNICALL JFN(deflateStreams)(JNIEnv* e, jclass c, jobjectA
     return res;
 }
 
+/* byte[][] zopfliStreams(byte[][] raw, int iterations, int splitting, int maxBlocks, long masterBlock):
+ * MultiCafeUndZopfliCompressor / MultiJZopfliCompressor.compressWithOptions for every buffer */
+JNIEXPORT jobjectArray JNICALL JFN(zopfliStreams)(JNIEnv* e, jclass c, jobjectArray raw, jint iterations, jint splitting, jint maxBlocks, jlong masterBlock) {
+    (void)c;
+    in_list L = {0};
+    jobjectArray res = NULL;
+    if (pin(e, raw, &L) == 0) {
+        uint8_t** out = calloc((size_t)L.n + 1, sizeof *out);
+        size_t* olen = calloc((size_t)L.n + 1, sizeof *olen);
+        if (d4g_zopfli_streams((size_t)L.n, L.ptr, L.len, iterations, splitting, maxBlocks, (size_t)masterBlock, out, olen) == D4G_OK) res = to_java(e, L.n, out, olen);
+        else throw_io(e, "d4g_zopfli_streams");
+        free(out); free(olen);
+    }
+    unpin(e, &L);
+    return res;
+}
+
 /* byte[][] compress(byte[][] raw, int mode, int iter, boolean mergeBlocks): CompressionUtil.compress for every buffer;
  * throws IOException("Unable to compress data") like CompressionUtil.java:177-179 */
 JNIEXPORT jobjectArray JNICALL JFN(compress)(JNIEnv* e, jclass c, jobjectArray raw, jint mode, jint iter, jboolean merge) {
