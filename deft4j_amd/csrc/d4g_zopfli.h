@@ -997,10 +997,57 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 bool fl = false;
                 if (p > start + ZF_MAXM + 1 && p + ZF_MAXM * 2 + 1 < end)
                     fl = zf_samecap(v.same[p], end, p) > ZF_MAXM * 2 && zf_samecap(v.same[p - ZF_MAXM], end, p - ZF_MAXM) > ZF_MAXM;
-                rMeta = (zf_best(v, p) >> 16) | ((uint32_t)n << 16) | (fl ? 1u << 24 : 0u);
+                rMeta = (zf_best(v, p) >> 16) | ((uint32_t)n << 16) | (fl ? 1u << 24 : 0u) | (n == 255 ? 1u << 25 : 0u);
             }
             loaded = B;
             LZ_WAVE_SYNC();
+        }
+        // the usual positions of this 64-block in a tight loop over registers 0..5: no long-run flag, at most eight change
+        // points.  Anything else leaves the loop for the general code below.
+        if (!afterShortcut) {
+            int o = j - B;
+            const int oEnd = size - B < 64 ? size - B : 64;
+            float cr[6];
+            uint32_t lr[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { cr[q] = C[q]; lr[q] = Ln[q]; }
+            for (; o < oEnd; o++) {
+                const uint32_t meta = zf_rl(rMeta, o);
+                if ((meta >> 24) != 0u) break;
+                const int leng = (int)(meta & 0xffff);
+                const int kend = leng >= 3 ? (leng < size - B - o ? leng : size - B - o) : 0;
+                const double cj = (double)zf_u2f(zf_rl(zf_f2u(cr[0]), o));
+                const double ncLit = zf_u2d((unsigned long long)zf_rl(rLitLo, o) | ((unsigned long long)zf_rl(rLitHi, o) << 32)) + cj;
+                {
+                    const double a0 = (double)cr[0], a1 = (double)cr[1];
+                    if (lane == o + 1 && ncLit < a0) { cr[0] = (float)ncLit; lr[0] = 1; }
+                    if (lane == o - 63 && ncLit < a1) { cr[1] = (float)ncLit; lr[1] = 1; }
+                }
+                if (kend >= 3) {
+                    const double mca = mincost + cj;
+                    const uint32_t c0 = zf_rl(rCl0, o), c1 = zf_rl(rCl1, o), c2 = zf_rl(rCl2, o), c3 = zf_rl(rCl3, o);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        if (q == 0 || o + kend >= 64 * q) {
+                            const int k = 64 * q + lane - o;
+                            const double cq = (double)cr[q];
+                            const bool isM = k >= 3 && k <= kend && !(cq <= mca);
+                            if (__ballot(isM) != 0ull) {
+                                const int kk = isM ? k : 3;
+                                const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
+                                               ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                                const int ib = S.lbTab[kk] + S.cpDb[o][ci];
+                                const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
+                                if (isM && nc < cq) { cr[q] = (float)nc; lr[q] = (uint32_t)k; }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) { C[q] = cr[q]; Ln[q] = lr[q]; }
+            j = B + o;
+            if (o >= oEnd) continue;
         }
         const int o = j - B;
         const uint32_t meta = zf_rl(rMeta, o);
