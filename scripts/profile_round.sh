@@ -15,3 +15,6 @@ D4G_LANES=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 D4G_LANES=1 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv -d $OUT/sq2 -- $B --steps 1 --warmup 0 > $OUT/sq2.log 2>&1
 D4G_BENCH_NOPOOL=1 rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt_c3 -- $B --workload config3 --members 64 --steps 1 --warmup 1 > $OUT/kt_c3.log 2>&1
 find $OUT -name "*.csv" | head -40
+# Zopfli kernels (mode ZOPFLI_EXTENSIVE on a 16 MB buffer, 20 iterations): kernel trace only
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt_c4 -- $B --workload config4 --bytes 16000000 --steps 1 --warmup 0 > $OUT/kt_c4.log 2>&1
+find $OUT/kt_c4 -name "*kernel_stats.csv" | head
