@@ -1477,13 +1477,22 @@ struct Batch {
     }
 
     void run(bool merge) {
+        run_parse(merge);
+        run_rest(merge);
+    }
+    // run() in two steps, for callers that start other work on the decoded bytes between them (the recompress modes)
+    double tRun0 = 0, tRun1 = 0;
+    void run_parse(bool merge) {
         if (ran) throw std::runtime_error("batch already ran");
         ran = true;
         engine().init();
-        double t0 = now_ms();
+        tRun0 = now_ms();
         parse_probe();
         build_blocks(merge, true);
-        double t1 = now_ms();
+        tRun1 = now_ms();
+    }
+    void run_rest(bool merge) {
+        const double t0 = tRun0, t1 = tRun1;
         phase1();
         double t2 = now_ms();
         if (merge) phase_merge();

@@ -1,6 +1,7 @@
 // libdeft4g.hip — the single translation unit of libdeft4g.so (kernels + host + C ABI).
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -o libdeft4g.so libdeft4g.hip
 #include <mutex>
+#include <thread>
 
 #include "d4g_host.h"
 #include "d4g_lz77_host.h"
@@ -596,7 +597,50 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     std::vector<LzSpec> specs;
     for (size_t i = 0; i < n; i++)
         for (int k : lzIdx) { LzSpec s = list[k]; s.input = (int32_t)i; specs.push_back(s); }
-    std::unique_ptr<d4g_batch> e1 = encode_batch(n, raw + i0, len + i0, fromDevice, specs, merge);
+    std::unique_ptr<d4g_batch> e1(new d4g_batch());
+    e1->lz.reset(new LzFront(e1->impl));
+    e1->lz->create(n, raw + i0, len + i0, specs.size(), specs.data(), fromDevice);
+    // stage 3 starts here, on its own host thread (its own HIP streams): the Zopfli compressors' outputs, encoded on the device
+    // and parsed + optimised like any other stream.  A squeeze keeps a handful of waves busy for a long time; the zlib-family
+    // stages below fill the rest of the device meanwhile.  It only reads the inputs (e1's dU, stable from create on).
+    struct ZStage {
+        std::unique_ptr<d4g_batch> e3;
+        std::exception_ptr err;
+        double ms = 0, msTable = 0, msSplit = 0, msSqueeze = 0, msEmit = 0;
+        int64_t blocks = 0, posIter = 0, outputs = 0;
+    } Z;
+    auto zopfli_stage = [&]() {
+        try {
+            bind_device();
+            double tz = now_ms();
+            std::vector<const uint8_t*> dp(n);
+            std::vector<i64> dl(n);
+            for (size_t i = 0; i < n; i++) { dp[i] = e1->impl.dU + e1->lz->rawU[i]; dl[i] = e1->lz->rawLen[i]; }
+            ZfFront zf;
+            zf.create(n, dp.data(), dl.data());
+            std::vector<ZfSpec> zs;
+            for (size_t i = 0; i < n; i++)
+                for (int k : zIdx) zs.push_back(zopfli_options(list[k], (int)i, R.iter));
+            zf.encode(zs);
+            Z.msTable = zf.msTable; Z.msSplit = zf.msSplit; Z.msSqueeze = zf.msSqueeze; Z.msEmit = zf.msEmit;
+            Z.blocks = zf.squeezeBlocks; Z.posIter = zf.squeezePositions; Z.outputs = (int64_t)zs.size();
+            std::vector<const uint8_t*> sp(zs.size());
+            std::vector<size_t> sl(zs.size());
+            for (size_t q = 0; q < zs.size(); q++) { sp[q] = (const uint8_t*)zf.outWords[q]; sl[q] = (size_t)((zf.outBits[q] + 7) / 8); }
+            Z.e3.reset(new d4g_batch());
+            Z.e3->impl.create(zs.size(), sp.data(), sl.data(), true);
+            Z.ms = now_ms() - tz;
+            Z.e3->impl.run(merge);
+        } catch (...) {
+            Z.err = std::current_exception();
+        }
+    };
+    std::thread zthread;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{zthread};   // also when a stage below throws
+#ifndef D4G_HOSTSIM
+    if (!zIdx.empty()) zthread = std::thread(zopfli_stage);
+#endif
+    e1->lz->run(true, merge);
     add_stats(R.agg, e1->impl.stats);
     R.outputsOptimised += (int64_t)specs.size();
     struct Best { long long bits = 0; int listIdx = -1; const Batch* owner = nullptr; int stream = -1; };
@@ -650,35 +694,24 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
                 for (size_t k = 0; k < hIdx.size(); k++) offer(need[q], hIdx[k], &e2->impl, (int)(q * hIdx.size() + k));
         }
     }
-    // stage 3: the Zopfli compressors' outputs, encoded on the device and parsed + optimised like any other stream
-    std::unique_ptr<d4g_batch> e3;
+    // stage 3's results
     if (!zIdx.empty()) {
-        double tz = now_ms();
-        std::vector<const uint8_t*> dp(n);
-        std::vector<i64> dl(n);
-        for (size_t i = 0; i < n; i++) { dp[i] = e1->impl.dU + e1->lz->rawU[i]; dl[i] = e1->lz->rawLen[i]; }
-        ZfFront zf;
-        zf.create(n, dp.data(), dl.data());
-        std::vector<ZfSpec> zs;
-        for (size_t i = 0; i < n; i++)
-            for (int k : zIdx) zs.push_back(zopfli_options(list[k], (int)i, R.iter));
-        zf.encode(zs);
-        R.msZfTable += zf.msTable; R.msZfSplit += zf.msSplit; R.msZfSqueeze += zf.msSqueeze; R.msZfEmit += zf.msEmit;
-        R.zfBlocks += zf.squeezeBlocks; R.zfPosIter += zf.squeezePositions;
-        std::vector<const uint8_t*> sp(zs.size());
-        std::vector<size_t> sl(zs.size());
-        for (size_t q = 0; q < zs.size(); q++) { sp[q] = (const uint8_t*)zf.outWords[q]; sl[q] = (size_t)((zf.outBits[q] + 7) / 8); }
-        e3.reset(new d4g_batch());
-        e3->impl.create(zs.size(), sp.data(), sl.data(), true);
-        R.msZopfli += now_ms() - tz;
-        e3->impl.run(merge);
-        add_stats(R.agg, e3->impl.stats);
-        R.outputsOptimised += (int64_t)zs.size();
+#ifdef D4G_HOSTSIM
+        zopfli_stage();            // the emulator runs one kernel at a time
+#else
+        zthread.join();
+#endif
+        if (Z.err) std::rethrow_exception(Z.err);
+        R.msZfTable += Z.msTable; R.msZfSplit += Z.msSplit; R.msZfSqueeze += Z.msSqueeze; R.msZfEmit += Z.msEmit;
+        R.zfBlocks += Z.blocks; R.zfPosIter += Z.posIter;
+        R.msZopfli += Z.ms;
+        add_stats(R.agg, Z.e3->impl.stats);
+        R.outputsOptimised += Z.outputs;
         for (size_t i = 0; i < n; i++)
             for (size_t k = 0; k < zIdx.size(); k++) {
                 const int st = (int)(i * zIdx.size() + k);
-                if (e3->impl.streams[st].status != 0) throw std::runtime_error("zopfli output does not parse");
-                offer(i, zIdx[k], &e3->impl, st);
+                if (Z.e3->impl.streams[st].status != 0) throw std::runtime_error("zopfli output does not parse");
+                offer(i, zIdx[k], &Z.e3->impl, st);
             }
     }
     for (size_t i = 0; i < n; i++) {
@@ -773,6 +806,8 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     const size_t n = A.streams.size();
     double t0 = now_ms();
     A.run(merge);                                      // container.optimise(mergeBlocks) — CMDUtil.java:70
+    // (Running this search on its own host thread next to the recompression was tried for the Zopfli modes: two merge chains'
+    // persistent kernels then spin against each other and config 4 went from 100 s to 126 s.)
     b->graft.assign(n, 0);
     b->recompSaved.assign(n, 0);
     b->reoptIndex.assign(n, -1);
@@ -780,6 +815,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     for (size_t i = 0; i < n; i++)
         if (A.streams[i].status == 0) ok.push_back(i);
     if (mode == D4G_MODE_NONE || ok.empty()) return;
+    const double tc0 = now_ms();
     // stream.getUncompressedData() -> compUtil.compress(uncompressed, true) — :83-84; the decoded bytes stay in HBM
     std::vector<const uint8_t*> rp(ok.size());
     std::vector<size_t> rl(ok.size());
@@ -808,7 +844,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     const d4g_stats& es = R.agg;
     A.stats.ms_lz_sort = es.ms_lz_sort; A.stats.ms_lz_parse = es.ms_lz_parse; A.stats.ms_lz_emit = es.ms_lz_emit;
     A.stats.lz_parse_passes = es.lz_parse_passes; A.stats.lz_chunks_rerun = es.lz_chunks_rerun; A.stats.lz_symbols = es.lz_symbols;
-    A.stats.ms_recompress_encode = t1 - (t0 + A.stats.ms_total);
+    A.stats.ms_recompress_encode = t1 - tc0;
     A.stats.ms_recompress_encode_front = es.ms_parse;
     A.stats.ms_recompress_encode_search = es.ms_optimise + es.ms_merge;
     A.stats.ms_recompress_reoptimise = now_ms() - t1;

@@ -37,6 +37,8 @@ def test_no_cpu_fallback_without_a_gpu(lib):
     assert b"no CPU fallback" in lib.d4g_last_error() or b"device" in lib.d4g_last_error()
     with pytest.raises(RuntimeError):
         deft4j_amd.Deft.optimiseDeflateStream(b"\x03\x00")
+    with pytest.raises(RuntimeError):
+        deft4j_amd.zopfli_streams([b"abc"], 3)           # the Zopfli encoder has no CPU path either
     # the raw entry points also refuse
     arr = (ctypes.c_char_p * 1)(b"\x03\x00")
     lens = (ctypes.c_size_t * 1)(2)
