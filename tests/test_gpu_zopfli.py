@@ -97,3 +97,14 @@ def test_recompress_graft_loop_in_mode_zopfli():
     for a, r in zip(streams, res):
         assert r == OC.recompress(a, True, D.MODE_ZOPFLI, 5), len(a)
     assert res[0]["recompress_saved"] > 0
+
+
+def test_batch_of_members_through_mode_zopfli_extensive():
+    """eight members in one d4g_compress call: the Zopfli stage (its own host thread) and the zlib-family stages run side by
+    side on the device; every member's winner and bytes equal the composed oracles'"""
+    import oracle_compose as OC
+    datas = [synth.reptext(48000, 500 + i) if i % 2 == 0 else synth.pngidat(40000, 700 + i, 200) for i in range(8)]
+    cu = D.CompressionUtil(D.MODE_ZOPFLI_EXTENSIVE, 4, True)
+    outs = cu.compress_many(datas)
+    for d, o, w in zip(datas, outs, cu.last_winner):
+        assert (o, w) == OC.compress(d, True, D.MODE_ZOPFLI_EXTENSIVE, 4), len(d)
