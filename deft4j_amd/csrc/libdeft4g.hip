@@ -806,8 +806,9 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     const size_t n = A.streams.size();
     double t0 = now_ms();
     A.run(merge);                                      // container.optimise(mergeBlocks) — CMDUtil.java:70
-    // (Running this search on its own host thread next to the recompression was tried for the Zopfli modes: two merge chains'
-    // persistent kernels then spin against each other and config 4 went from 100 s to 126 s.)
+    // (Overlapping this search with the recompression was tried for the Zopfli modes, both on a third host thread and on this
+    // thread once the Zopfli stage is under way: config 4 went from 100 s to 125 s either way — the optimiser's kernels run
+    // 2.5-3x slower while a squeeze kernel is resident, so the less of the merge chains overlaps it the better.)
     b->graft.assign(n, 0);
     b->recompSaved.assign(n, 0);
     b->reoptIndex.assign(n, -1);
