@@ -15,6 +15,9 @@
 #endif
 
 #define D4G_DEV __device__ __forceinline__
+// Issue priority of the optimiser's waves (s_setprio): above the default 0, so that they are not starved by an old, always-ready
+// wave of another kernel on the same SIMD (the Zopfli squeeze runs for minutes); serial sections go to 3 and come back here.
+#define D4G_BASE_PRIO 1
 
 // ---------------------------------------------------------------------------------------
 // RFC 1951 symbol arithmetic (B/deflate/Constants.java:9-23,65-128) — closed forms instead
@@ -544,7 +547,7 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
         int err = 0;
         if (lane == 0) err = d4g_tree_finish(m, 1, 0, nl, root, numSymbols, limit, outLen);
 #ifndef D4G_HOSTSIM
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
 #endif
         return __shfl(err, 0);
     }
@@ -557,7 +560,7 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
         }
     }
 #ifndef D4G_HOSTSIM
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
 #endif
     return 0;
 }

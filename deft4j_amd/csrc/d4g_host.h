@@ -1492,7 +1492,7 @@ struct Batch {
         tRun1 = now_ms();
     }
     void run_rest(bool merge) {
-        const double t0 = tRun0, t1 = tRun1;
+        const double t0 = tRun0, t1 = tRun1, t1b = now_ms();   // (other work may have run between the two steps)
         phase1();
         double t2 = now_ms();
         if (merge) phase_merge();
@@ -1500,10 +1500,10 @@ struct Batch {
         phase_write();
         double t4 = now_ms();
         stats.ms_parse = t1 - t0;
-        stats.ms_optimise = t2 - t1;
+        stats.ms_optimise = t2 - t1b;
         stats.ms_merge = t3 - t2;
         stats.ms_write = t4 - t3;
-        stats.ms_total = t4 - t0;
+        stats.ms_total = (t1 - t0) + (t4 - t1b);
         stats.ms_search_kernels = msSearch;
         stats.ms_parse_kernels = msParseKernels;
         stats.search_bytes_algorithmic = stats.bytes_in + stats.bytes_decoded + stats.bytes_out;

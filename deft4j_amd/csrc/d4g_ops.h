@@ -909,7 +909,7 @@ __device__ __forceinline__ void wg_rewrite_header(D4GLds* L, int flags) {
         d4g_wave_sync();
         w0_remove_trailing_header_codes(S);
 #ifndef D4G_HOSTSIM
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
 #endif
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
         if (lane == 0) {
@@ -1446,6 +1446,9 @@ D4G_DEV bool d4g_map_wg(int nActive, int nOpsLevel, int tileGroups, int& blkSlot
 #define D4G_STATE_WAVES 8
 #endif
 __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_STATE_WAVES) k_exec_state_ops(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
     __shared__ D4GLds L;
     int bs, orel;
     if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
@@ -1455,6 +1458,9 @@ __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_STATE_WAVES) k_exe
 // Same body for the token-pass-only ops (optimise / least-expensive pruning): they have no single-lane
 // section, so they run with wide workgroups (up to 16 waves sweep the block's tokens together).
 __global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
     __shared__ D4GLds L;
     int bs, orel;
     if (!d4g_map_wg(c.nActive, nOpsLevel, c.tileGroups, bs, orel)) return;
@@ -1467,6 +1473,9 @@ __global__ void __launch_bounds__(1024) k_exec_state_ops_wide(D4GCtx c, const in
 #define D4G_PERSIST_WAVES 4
 #endif
 __global__ void __launch_bounds__(256) D4G_WAVES_PER_SIMD(D4G_PERSIST_WAVES) k_persist_state_ops(D4GCtx c, D4GQueue q) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
     __shared__ D4GLds L;
     __shared__ int sTask[3], sOk;
     int cursor = 0;
@@ -1785,6 +1794,9 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
 }
 
 __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t* opList, int nOpsLevel) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
     __shared__ D4GHdrLds H;
     __shared__ __attribute__((aligned(16))) uint8_t comb[D4G_NLIT + D4G_NDIST];   // (compared word-wise against the memo's key)
     int bs, orel;
@@ -1793,6 +1805,9 @@ __global__ void __launch_bounds__(64) k_exec_hdr_search(D4GCtx c, const int32_t*
 }
 
 __global__ void __launch_bounds__(64) k_persist_hdr_search(D4GCtx c, D4GQueue q) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
     __shared__ D4GHdrLds H;
     __shared__ __attribute__((aligned(16))) uint8_t comb[D4G_NLIT + D4G_NDIST];   // (compared word-wise against the memo's key)
     __shared__ int sTask[3], sOk;

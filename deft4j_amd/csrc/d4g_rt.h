@@ -26,6 +26,7 @@
 // per-thread stream sets).  Batches are driven by whichever host thread calls in — CompressionUtil's pool threads
 // (C/CompressionUtil.java:111-117), or two bench threads keeping two batches in flight — and each thread gets its own
 // HIP streams, so independent batches overlap on the device instead of queueing behind one library-wide lock.
+inline bool& rt_low_priority_thread() { thread_local bool v = false; return v; }   // set before the thread's first runtime call
 struct RtGlobals;
 struct RtProcess {
     int device = -1;
@@ -61,9 +62,19 @@ struct RtGlobals {
     void ensure() {   // the calling thread's streams, created on first use after d4g_init
         if (made || !ready) return;
         RT_CHECK(hipSetDevice(device));
+        // A thread that is about to run kernels lasting minutes (the Zopfli squeeze) asks for low-priority streams: HIP multiplexes
+        // its streams onto a few hardware queues per priority level, and a queue stays busy until its kernel ends — normal-priority
+        // streams of other threads that landed on the same queue would wait behind it (measured: a candidate search held up for 78 s).
+        int least = 0, greatest = 0;
+        if (rt_low_priority_thread()) RT_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         for (int k = 0; k < RT_MAX_LANES; k++) {
-            RT_CHECK(hipStreamCreateWithFlags(&a[k], hipStreamNonBlocking));
-            RT_CHECK(hipStreamCreateWithFlags(&b[k], hipStreamNonBlocking));
+            if (rt_low_priority_thread()) {
+                RT_CHECK(hipStreamCreateWithPriority(&a[k], hipStreamNonBlocking, least));
+                RT_CHECK(hipStreamCreateWithPriority(&b[k], hipStreamNonBlocking, least));
+            } else {
+                RT_CHECK(hipStreamCreateWithFlags(&a[k], hipStreamNonBlocking));
+                RT_CHECK(hipStreamCreateWithFlags(&b[k], hipStreamNonBlocking));
+            }
         }
         made = true;
     }

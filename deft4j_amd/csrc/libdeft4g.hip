@@ -1,5 +1,6 @@
 // libdeft4g.hip — the single translation unit of libdeft4g.so (kernels + host + C ABI).
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -o libdeft4g.so libdeft4g.hip
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -585,7 +586,7 @@ std::unique_ptr<d4g_batch> encode_batch(size_t n, const uint8_t* const* raw, con
 }
 // one group of inputs [i0, i1)
 void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* raw, const size_t* len, bool fromDevice,
-                    const std::vector<LzSpec>& list, bool merge) {
+                    const std::vector<LzSpec>& list, bool merge, const std::function<void()>& afterStart) {
     const size_t n = i1 - i0;
     // stage 1: every compressor output that can hold back-references
     std::vector<int> lzIdx, hIdx;   // list positions
@@ -611,6 +612,9 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     } Z;
     auto zopfli_stage = [&]() {
         try {
+#ifndef D4G_HOSTSIM
+            rt_low_priority_thread() = true;      // this thread's streams carry kernels that run for minutes (d4g_rt.h)
+#endif
             bind_device();
             double tz = now_ms();
             std::vector<const uint8_t*> dp(n);
@@ -640,7 +644,13 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
 #ifndef D4G_HOSTSIM
     if (!zIdx.empty()) zthread = std::thread(zopfli_stage);
 #endif
+    const bool dbg = env_int("D4G_DEBUG_ZOPFLI", 0) > 0;
+    const double tg0 = now_ms();
+    if (afterStart) afterStart();      // the caller's own work that only had to wait for the Zopfli stage to be under way
+    if (dbg) fprintf(stderr, "[group] +%.1f s: caller's work done\n", (now_ms() - tg0) / 1000);
     e1->lz->run(true, merge);
+    if (dbg) fprintf(stderr, "[group] +%.1f s: zlib-family stage 1 done (front %.1f s, search %.1f s, merge %.1f s)\n", (now_ms() - tg0) / 1000,
+                     e1->impl.stats.ms_parse / 1000, e1->impl.stats.ms_optimise / 1000, e1->impl.stats.ms_merge / 1000);
     add_stats(R.agg, e1->impl.stats);
     R.outputsOptimised += (int64_t)specs.size();
     struct Best { long long bits = 0; int listIdx = -1; const Batch* owner = nullptr; int stream = -1; };
@@ -699,7 +709,10 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
 #ifdef D4G_HOSTSIM
         zopfli_stage();            // the emulator runs one kernel at a time
 #else
+        if (dbg) fprintf(stderr, "[group] +%.1f s: stage 2 done, waiting for the Zopfli stage\n", (now_ms() - tg0) / 1000);
         zthread.join();
+        if (dbg) fprintf(stderr, "[group] +%.1f s: Zopfli stage joined (encode %.1f s, its outputs' search %.1f s + merge %.1f s)\n", (now_ms() - tg0) / 1000,
+                         Z.ms / 1000, Z.e3 ? Z.e3->impl.stats.ms_optimise / 1000 : 0.0, Z.e3 ? Z.e3->impl.stats.ms_merge / 1000 : 0.0);
 #endif
         if (Z.err) std::rethrow_exception(Z.err);
         R.msZfTable += Z.msTable; R.msZfSplit += Z.msSplit; R.msZfSqueeze += Z.msSqueeze; R.msZfEmit += Z.msEmit;
@@ -727,8 +740,11 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     }
     rt_sync();
 }
-void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, int iter, bool merge) {
+void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, int mode, int iter, bool merge,
+                  const std::function<void()>& between = nullptr) {
     R.iter = iter;
+    int betweenState = 0;      // 0 not run, 1 running, 2 done
+    std::function<void()> once = [&]() { if (between && betweenState == 0) { betweenState = 1; between(); betweenState = 2; } };
     std::vector<LzSpec> list;
     std::string why;
     if (!mode_specs(mode, list, why)) throw std::runtime_error(why);
@@ -752,13 +768,14 @@ void compress_run(CompressRun& R, size_t n, const uint8_t* const* raw, const siz
             i1++;
         }
         try {
-            compress_group(R, i0, i1, raw, len, fromDevice, list, merge);
+            compress_group(R, i0, i1, raw, len, fromDevice, list, merge, once);
             i0 = i1;
         } catch (const std::runtime_error& ex) {
-            if (strstr(ex.what(), "hipMalloc") && i1 - i0 > 1) { shrink *= 2; continue; }   // group too large for the device: retry smaller
+            if (betweenState != 1 && strstr(ex.what(), "hipMalloc") && i1 - i0 > 1) { shrink *= 2; continue; }   // group too large for the device: retry smaller
             throw;
         }
     }
+    once();
 }
 uint8_t* copy_stream_out(Batch& b, size_t i, size_t* len) {
     const HStream& s = b.streams[i];
@@ -805,24 +822,25 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     Batch& A = b->impl;
     const size_t n = A.streams.size();
     double t0 = now_ms();
-    A.run(merge);                                      // container.optimise(mergeBlocks) — CMDUtil.java:70
-    // (Overlapping this search with the recompression was tried for the Zopfli modes, both on a third host thread and on this
-    // thread once the Zopfli stage is under way: config 4 went from 100 s to 125 s either way — the optimiser's kernels run
-    // 2.5-3x slower while a squeeze kernel is resident, so the less of the merge chains overlaps it the better.)
+    // container.optimise(mergeBlocks) — CMDUtil.java:70.  In a Zopfli mode only the parse happens here: the search of the originals
+    // runs once the Zopfli stage of the recompression (its own host thread, a few long-running waves) is under way.
+    const bool deferSearch = mode >= D4G_MODE_ZOPFLI;
+    A.run_parse(merge);
+    if (!deferSearch) A.run_rest(merge);
     b->graft.assign(n, 0);
     b->recompSaved.assign(n, 0);
     b->reoptIndex.assign(n, -1);
     std::vector<size_t> ok;
     for (size_t i = 0; i < n; i++)
         if (A.streams[i].status == 0) ok.push_back(i);
-    if (mode == D4G_MODE_NONE || ok.empty()) return;
+    if (mode == D4G_MODE_NONE || ok.empty()) { if (deferSearch) A.run_rest(merge); return; }
     const double tc0 = now_ms();
     // stream.getUncompressedData() -> compUtil.compress(uncompressed, true) — :83-84; the decoded bytes stay in HBM
     std::vector<const uint8_t*> rp(ok.size());
     std::vector<size_t> rl(ok.size());
     for (size_t k = 0; k < ok.size(); k++) { rp[k] = A.dU + A.streams[ok[k]].uBase; rl[k] = (size_t)A.streams[ok[k]].nU; }
     CompressRun R;
-    compress_run(R, ok.size(), rp.data(), rl.data(), true, mode, iter, merge);
+    compress_run(R, ok.size(), rp.data(), rl.data(), true, mode, iter, merge, deferSearch ? std::function<void()>([&]() { A.run_rest(merge); }) : std::function<void()>());
     double t1 = now_ms();
     // new DeflateStream().parse(recompressed); recompStream.optimise(mergeBlocks) — :85-89
     std::vector<const uint8_t*> wp(ok.size());
@@ -845,7 +863,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
     const d4g_stats& es = R.agg;
     A.stats.ms_lz_sort = es.ms_lz_sort; A.stats.ms_lz_parse = es.ms_lz_parse; A.stats.ms_lz_emit = es.ms_lz_emit;
     A.stats.lz_parse_passes = es.lz_parse_passes; A.stats.lz_chunks_rerun = es.lz_chunks_rerun; A.stats.lz_symbols = es.lz_symbols;
-    A.stats.ms_recompress_encode = t1 - tc0;
+    A.stats.ms_recompress_encode = t1 - tc0 - (deferSearch ? A.stats.ms_total - A.stats.ms_parse : 0.0);
     A.stats.ms_recompress_encode_front = es.ms_parse;
     A.stats.ms_recompress_encode_search = es.ms_optimise + es.ms_merge;
     A.stats.ms_recompress_reoptimise = now_ms() - t1;

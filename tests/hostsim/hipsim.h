@@ -140,6 +140,7 @@ inline void rt_h2d(void* d, const void* h, size_t n) { if (n) memcpy(d, h, n); }
 inline void rt_d2h(void* h, const void* d, size_t n) { if (n) memcpy(h, d, n); }
 inline void rt_d2d(void* d, const void* s, size_t n) { if (n) memmove(d, s, n); }
 inline void rt_memset(void* d, int v, size_t n) { if (n) memset(d, v, n); }
+inline bool& rt_low_priority_thread() { static bool v = false; return v; }
 inline void rt_sync() {}
 inline void rt_sync_all() {}
 struct RtEvent { void record() {} void record2() {} };  // timing is meaningless in the emulator
