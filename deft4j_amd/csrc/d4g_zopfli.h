@@ -43,6 +43,11 @@ struct ZfInput {
     uint16_t* val;           // 3-byte hash of every position
     uint16_t* same;          // following bytes equal to this one (capped at 65535), relative to the input's end
     uint16_t* lead;          // per ZF_KEY_TILE tile: length of its leading run
+    uint16_t* val2;          // the second hash ((same - 3) & 255) ^ val, with `same` relative to the input's end
+    // per 32 Ki-position sort block and per hash kind (0: val, 1: val2): positions ordered by (key, position)
+    uint16_t* sorted[2];     // [position slot] position within its sort block, bucket after bucket
+    uint16_t* rank[2];       // [position] its slot within the sort block
+    uint16_t* bstart[2];     // [sort block * 32768 + key] first slot of the key's bucket
     uint32_t* table;         // 8 words per position: change points (len << 16 | dist), ascending; 0 = unused;
                              // word 7 = ZF_POOL_LINK | index of the remaining points in `pool`
     uint32_t* best;          // (longest length << 16) | its distance; 0 when shorter than 3
@@ -112,7 +117,9 @@ __global__ void __launch_bounds__(256) k_zf_keys_b(const ZfInput* inputs, const 
                 if (l < tl) break;
             }
         }
-        in.same[p] = (uint16_t)(s > 65535 ? 65535 : s);
+        const int sm = (int)(s > 65535 ? 65535 : s);
+        in.same[p] = (uint16_t)sm;
+        in.val2[p] = (uint16_t)((((sm - 3) & 255) ^ zf_hash3(in.data, p)) & 32767);
     }
 }
 
@@ -232,6 +239,220 @@ __global__ void __launch_bounds__(ZF_MATCH_THREADS) k_zf_match(const ZfInput* in
         }
         LZ_WAVE_SYNC();
         // entry: the change points of length >= 3
+        int skip = 0;
+        while (skip < ncp && (int)(cps[skip] >> 16) < 3) skip++;
+        const int n3 = ncp - skip;
+        uint32_t* ent = job.table + (long long)pi * 8;
+        uint32_t link = 0;
+        if (n3 > 8) {
+            uint32_t at = 0;
+            if (lane == 0) {
+                at = atomicAdd(pool.used, (uint32_t)(n3 - 7 + 1));
+                if (at + (uint32_t)(n3 - 7 + 1) > pool.cap) { atomicAdd(pool.error, 1); at = 0xffffffffu; }
+            }
+            at = __shfl(at, 0);
+            if (at != 0xffffffffu) {
+                for (int k = lane; k < n3 - 7; k += 64) pool.words[at + k] = cps[skip + 7 + k];
+                if (lane == 0) pool.words[at + n3 - 7] = 0;
+                link = ZF_POOL_LINK | at;
+            }
+        }
+        if (lane < 8) {
+            uint32_t v = 0;
+            if (lane < n3 && (lane < 7 || n3 <= 8)) v = cps[skip + lane];
+            if (lane == 7 && n3 > 8) v = link;
+            ent[lane] = v;
+        }
+        if (lane == 0) job.best[pi] = best >= 3 ? (((uint32_t)best << 16) | (uint32_t)bestDist) : 0u;
+        LZ_WAVE_SYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The shared table (block end = input end) without the window scan: both hash chains are enumerated from buckets.
+// k_zf_sort orders the positions of a 32 Ki sort block by (key, position) — k_lz_sort's counting sort with the key read from an
+// array — once for the first hash and once for the second; a position's chain is then the part of its bucket below its own slot,
+// followed by the previous sort block's bucket from the top (positions further back are out of the window).
+// ---------------------------------------------------------------------------------------------------------------
+#define ZF_SORT_BLOCK 32768
+#define ZF_SORT_THREADS 512
+struct ZfSortJob { int32_t input, blk, kind, pad; };
+__global__ void __launch_bounds__(ZF_SORT_THREADS) k_zf_sort(const ZfInput* inputs, const ZfSortJob* jobs) {
+    __shared__ uint16_t tbl[32768];          // counts, then bucket cursors
+    __shared__ unsigned part[ZF_SORT_THREADS];
+    const ZfSortJob job = jobs[blockIdx.x];
+    const ZfInput in = inputs[job.input];
+    const long long p0 = (long long)job.blk * ZF_SORT_BLOCK;
+    const int nIns = (int)((in.n - p0) < ZF_SORT_BLOCK ? (in.n - p0) : ZF_SORT_BLOCK);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint16_t* key = (job.kind ? in.val2 : in.val) + p0;
+    unsigned* tw = (unsigned*)tbl;
+    for (int i = tid; i < 16384; i += ZF_SORT_THREADS) tw[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nIns; i += ZF_SORT_THREADS) {
+        const unsigned h = key[i];
+        atomicAdd(tw + (h >> 1), 1u << ((h & 1) * 16));   // two 16-bit counters per word; a count is at most 32768
+    }
+    __syncthreads();
+    unsigned sum = 0;
+    for (int k = 0; k < 32; k++) { unsigned w = tw[tid * 32 + k]; sum += (w & 0xffffu) + (w >> 16); }
+    part[tid] = sum;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned loc[8], sacc = 0;
+        for (int k = 0; k < 8; k++) { loc[k] = sacc; sacc += part[tid * 8 + k]; }
+        unsigned inc = sacc;
+        for (int dd = 1; dd < 64; dd <<= 1) { unsigned o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+        const unsigned excl = inc - sacc;
+        for (int k = 0; k < 8; k++) part[tid * 8 + k] = excl + loc[k];
+    }
+    __syncthreads();
+    {
+        unsigned run = part[tid];
+        uint16_t* bs = in.bstart[job.kind] + (long long)job.blk * ZF_SORT_BLOCK;
+        for (int k = 0; k < 32; k++) {
+            const unsigned w = tw[tid * 32 + k];
+            const unsigned a = run, b = run + (w & 0xffffu);
+            run = b + (w >> 16);
+            tw[tid * 32 + k] = (a & 0xffffu) | (b << 16);
+            bs[tid * 64 + 2 * k] = (uint16_t)a;
+            bs[tid * 64 + 2 * k + 1] = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // placement in position order by one wave, 64 positions per step (as k_lz_sort: lane tags find the lanes that share a key)
+    volatile uint16_t* vt = tbl;
+    uint16_t* Sout = in.sorted[job.kind] + p0;
+    uint16_t* Rout = in.rank[job.kind] + p0;
+    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    for (int i0 = 0; i0 < nIns; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < nIns;
+        const unsigned h = valid ? key[i] : 0u;
+        const unsigned cur = valid ? vt[h] : 0u;
+        LZ_WAVE_SYNC();
+        if (valid) vt[h] = (uint16_t)(0x8000u | (unsigned)lane);
+        LZ_WAVE_SYNC();
+        const unsigned w = valid ? vt[h] : 0u;
+        LZ_WAVE_SYNC();
+        if (valid && (w & 63u) != (unsigned)lane) vt[h] = (uint16_t)(0xC000u | (unsigned)lane);
+        LZ_WAVE_SYNC();
+        const unsigned w2 = valid ? vt[h] : 0u;
+        LZ_WAVE_SYNC();
+        const bool dup = valid && (w2 & 0x4000u);
+        unsigned rank = cur;
+        if (valid && !dup) vt[h] = (uint16_t)(cur + 1);
+        unsigned long long rem = __ballot(dup);
+        while (rem) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const unsigned hh = __shfl(h, leader);
+            const unsigned long long m = __ballot(dup && h == hh);
+            if (dup && h == hh) {
+                rank = cur + (unsigned)__popcll(m & below);
+                if ((m >> lane) == 1ULL) vt[h] = (uint16_t)(cur + (unsigned)__popcll(m));
+            }
+            rem &= ~m;
+        }
+        LZ_WAVE_SYNC();
+        if (valid) {
+            Rout[i] = (uint16_t)rank;
+            Sout[rank] = (uint16_t)i;
+        }
+    }
+}
+
+// slot range [lo, hi) of `key`'s bucket in sort block `blk`
+D4G_DEV void zf_bucket(const ZfInput& in, int kind, long long blk, int key, int& lo, int& hi) {
+    const uint16_t* bs = in.bstart[kind] + blk * ZF_SORT_BLOCK;
+    const long long p0 = blk * ZF_SORT_BLOCK;
+    const int nIns = (int)((in.n - p0) < ZF_SORT_BLOCK ? (in.n - p0) : ZF_SORT_BLOCK);
+    lo = bs[key];
+    hi = key == 32767 ? nIns : bs[key + 1];
+    if (hi < lo) hi = nIns;      // (a bucket start of 32768 does not fit 16 bits: only the empty buckets behind a full block's single key)
+}
+
+#define ZF_MS_THREADS 256
+struct ZfMatchSortedLds { uint32_t cps[ZF_MS_THREADS / 64][264]; };
+__global__ void __launch_bounds__(ZF_MS_THREADS) k_zf_match_sorted(const ZfInput* inputs, const ZfMatchJob* jobs, ZfPool pool) {
+    __shared__ ZfMatchSortedLds L;
+    const ZfMatchJob job = jobs[blockIdx.x];
+    const ZfInput in = inputs[job.input];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t* cps = L.cps[wave];
+    for (int pi = wave; pi < job.count; pi += nw) {
+        const long long p = job.first + pi;
+        const int limit = (int)((in.n - p) < ZF_MAXM ? (in.n - p) : ZF_MAXM);
+        int best = 1, bestDist = 0, ncp = 0;
+        if (limit >= 3) {
+            const int key1 = in.val[p], key2 = in.val2[p], sp = in.same[p];
+            const long long lo = p - (ZF_WSIZE - 1) < 0 ? 0 : p - (ZF_WSIZE - 1);
+            int mode = 1, hits = 0;
+            // the current chain as two descending runs: slots [aLo, aHi) of sort block blkA, then [bLo, bHi) of the block before it
+            long long blkA = p >> 15;
+            int aLo, aHi, bLo = 0, bHi = 0;
+            zf_bucket(in, 0, blkA, key1, aLo, aHi);
+            aHi = in.rank[0][p];                                  // below the position's own slot
+            if (blkA > 0) zf_bucket(in, 0, blkA - 1, key1, bLo, bHi);
+            bool done = false;
+            int taken = 0;                                         // candidates of the current chain consumed so far
+            while (!done) {
+                const int nA = aHi - aLo, nB = bHi - bLo;
+                const int i = taken + lane;
+                long long q = -1;
+                if (i < nA) q = blkA * ZF_SORT_BLOCK + in.sorted[0 + (mode == 2)][blkA * ZF_SORT_BLOCK + (aHi - 1 - i)];
+                else if (i < nA + nB) q = (blkA - 1) * ZF_SORT_BLOCK + in.sorted[0 + (mode == 2)][(blkA - 1) * ZF_SORT_BLOCK + (bHi - 1 - (i - nA))];
+                const bool member = q >= lo;                        // (q = -1 when the chain has ended; positions descend, so the rest is out too)
+                const unsigned long long memb = __ballot(member);
+                if (!memb) break;
+                const bool m2 = mode == 1 && member && in.val2[q] == key2;
+                // lz77.c's quick reject: a candidate that differs at offset `bestlength` cannot set a record, and only records matter
+                int len = 0;
+                if (member && in.data[q + best] == in.data[p + best]) len = zf_match_len(in.data, p, q, limit);
+                const int pm = wave_incl_max_i32(member ? len : 0);
+                const int run = pm > best ? pm : best;
+                const int idx = __popcll(memb & ((1ull << lane) - 1ull));
+                const bool isBreak = member && len >= limit;
+                const bool hitStop = member && (hits + idx + 1 >= ZF_MAX_HITS);
+                const bool isSwitch = m2 && run >= sp;
+                const unsigned long long stopM = __ballot(isBreak || hitStop), swM = __ballot(isSwitch);
+                const int ls = stopM ? __ffsll((long long)stopM) - 1 : 64, lw = swM ? __ffsll((long long)swM) - 1 : 64;
+                const int e = ls < lw ? ls : lw;
+                const unsigned long long upto = e >= 63 ? ~0ull : ((2ull << e) - 1ull);
+                int ex = __shfl_up(pm, 1);
+                if (lane == 0) ex = 0;
+                const int before = ex > best ? ex : best;
+                const bool rec = member && ((upto >> lane) & 1ull) && len > before;
+                const unsigned long long recM = __ballot(rec);
+                if (rec) {
+                    const int r = ncp + __popcll(recM & ((1ull << lane) - 1ull));
+                    if (r < 264) cps[r] = ((uint32_t)len << 16) | (uint32_t)(p - q);
+                }
+                if (recM) {
+                    const int last = 63 - __clzll((long long)recM);
+                    best = __shfl(len, last);
+                    bestDist = (int)__shfl((int)(p - q), last);
+                    ncp += __popcll(recM);
+                }
+                hits += __popcll(memb & upto);
+                if (ls <= lw && ls < 64) { done = true; break; }
+                if (lw < 64) {
+                    // the walk moves to the second chain at this node: what lies below it in its bucket of the second hash
+                    const long long qs = __shfl(q, lw);
+                    mode = 2;
+                    blkA = qs >> 15;
+                    zf_bucket(in, 1, blkA, key2, aLo, aHi);
+                    aHi = in.rank[1][qs];
+                    bLo = bHi = 0;
+                    if (blkA > 0 && blkA == (p >> 15)) zf_bucket(in, 1, blkA - 1, key2, bLo, bHi);
+                    taken = 0;
+                    continue;
+                }
+                if (memb != ~0ull) break;                            // the chain ended inside this step
+                taken += 64;
+            }
+        }
+        LZ_WAVE_SYNC();
         int skip = 0;
         while (skip < ncp && (int)(cps[skip] >> 16) < 3) skip++;
         const int n3 = ncp - skip;

@@ -56,6 +56,13 @@ struct ZfFront {
             in.val = dalloc<uint16_t>((size_t)len[i] + 8);
             in.same = dalloc<uint16_t>((size_t)len[i] + 8);
             in.lead = dalloc<uint16_t>((size_t)tiles + 1);
+            in.val2 = dalloc<uint16_t>((size_t)len[i] + 8);
+            const i64 sblocks = (len[i] + ZF_SORT_BLOCK - 1) / ZF_SORT_BLOCK;
+            for (int kind = 0; kind < 2; kind++) {
+                in.sorted[kind] = dalloc<uint16_t>((size_t)sblocks * ZF_SORT_BLOCK + 8);
+                in.rank[kind] = dalloc<uint16_t>((size_t)sblocks * ZF_SORT_BLOCK + 8);
+                in.bstart[kind] = dalloc<uint16_t>((size_t)sblocks * ZF_SORT_BLOCK + 8);
+            }
             in.table = dalloc<uint32_t>((size_t)len[i] * 8 + 8);
             in.best = dalloc<uint32_t>((size_t)len[i] + 8);
             for (i64 t = 0; t < tiles; t++) kj.push_back({(int32_t)i, (int32_t)t});
@@ -71,11 +78,35 @@ struct ZfFront {
             RT_LAUNCH(k_zf_keys_a, kj.size(), 256, dIn, dK);
             RT_LAUNCH(k_zf_keys_b, kj.size(), 256, dIn, dK);
         }
+        // the shared table: chains enumerated from sorted buckets (D4G_ZF_TABLE=scan: the window-scan kernel the tails use)
+        static const bool scanTable = getenv("D4G_ZF_TABLE") && !strcmp(getenv("D4G_ZF_TABLE"), "scan");
         std::vector<ZfMatchJob> mj;
-        for (size_t i = 0; i < n; i++)
-            for (i64 p = 0; p < len[i]; p += ZF_TILE)
-                mj.push_back({(int32_t)i, (int32_t)std::min<i64>(ZF_TILE, len[i] - p), p, len[i], hIn[i].table + p * 8, hIn[i].best + p});
-        run_match(mj);
+        if (scanTable) {
+            for (size_t i = 0; i < n; i++)
+                for (i64 p = 0; p < len[i]; p += ZF_TILE)
+                    mj.push_back({(int32_t)i, (int32_t)std::min<i64>(ZF_TILE, len[i] - p), p, len[i], hIn[i].table + p * 8, hIn[i].best + p});
+            run_match(mj);
+        } else {
+            std::vector<ZfSortJob> sj;
+            for (size_t i = 0; i < n; i++)
+                for (i64 b = 0; b * ZF_SORT_BLOCK < len[i]; b++)
+                    for (int kind = 0; kind < 2; kind++) sj.push_back({(int32_t)i, (int32_t)b, kind, 0});
+            if (!sj.empty()) {
+                ZfSortJob* dS = upload(sj);
+                RT_LAUNCH(k_zf_sort, sj.size(), ZF_SORT_THREADS, dIn, dS);
+            }
+            const i64 per = 1024;
+            for (size_t i = 0; i < n; i++)
+                for (i64 p = 0; p < len[i]; p += per)
+                    mj.push_back({(int32_t)i, (int32_t)std::min<i64>(per, len[i] - p), p, len[i], hIn[i].table + p * 8, hIn[i].best + p});
+            if (!mj.empty()) {
+                ZfMatchJob* dM = upload(mj);
+                RT_LAUNCH(k_zf_match_sorted, mj.size(), ZF_MS_THREADS, dIn, dM, pool);
+                int32_t err = 0;
+                rt_d2h(&err, pool.error, 4);
+                if (err) throw std::runtime_error("zopfli match table: change-point pool exhausted");
+            }
+        }
         msTable += now_ms() - t0;
     }
     void run_match(const std::vector<ZfMatchJob>& mj) {

@@ -1,7 +1,7 @@
 """Randomised parity run of the Zopfli encoder kernels against the oracle (portable log flavour) on the GPU.
 Data shapes are chosen to hit the special paths: long byte runs (the 258-shortcut, the run-length second hash, `same` capped at
 65535), block ends inside runs (tail tables), chain-hit caps, stored / fixed-tree blocks, tiny inputs, several master blocks.
-    python scripts/gpu_fuzz_zopfli.py [seconds] [seed]"""
+    python scripts/gpu_fuzz_zopfli.py [seconds] [seed] [--big]     (--big: inputs up to 400 KB, several master blocks, few iterations)"""
 import os
 import random
 import sys
@@ -57,7 +57,10 @@ def main():
         split = rng.randrange(3)
         maxb = rng.choice((15, 15, 0, 3))
         nmax = rng.choice((300, 2000, 12000, 40000))
-        datas = [shape(rng, rng.randrange(0, nmax)) for _ in range(rng.randrange(1, 7))]
+        if "--big" in sys.argv:
+            nmax = rng.choice((70000, 150000, 400000))
+            it = rng.choice((1, 2, 3))
+        datas = [shape(rng, rng.randrange(0, nmax)) for _ in range(rng.randrange(1, 7 if nmax < 50000 else 3))]
         longest = max(len(d) for d in datas)
         master = rng.choice((8 << 20, 1000000, max(1, longest // 3 + 1), max(1, rng.randrange(1, longest + 2))))
         got = D.zopfli_streams(datas, it, split, maxb, master)
