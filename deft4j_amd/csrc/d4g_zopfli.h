@@ -5,13 +5,15 @@
 // test/asyoulik/asyoulik-zopfli.txt.gz).
 //
 // Re-designed for the GPU rather than translated:
-//  * Zopfli's hash chains (3-byte hash + the run-length "second hash") become a window scan: the (hash, run length)
-//    keys of the 32 Ki positions before a tile sit in LDS and every wave tests 64 of them per step, replaying the chain
-//    walk (first-hash chain, the switch to the second chain, the 8192-hit cap, the stop at `limit`) with ballots and
-//    a prefix maximum.  The result of every search — the (length, distance) change points of `sublen` — is stored once
-//    per input position ("match table") and shared by every block-splitting option and squeeze iteration; Zopfli's
-//    longest-match cache memoises the same function per block.  Positions whose result depends on where their block
-//    ends (the last 258 bytes, or a byte run that crosses the end) are searched again per block ("tail tables").
+//  * Zopfli's hash chains (3-byte hash + the run-length "second hash") become sorted buckets: the positions of every 32 Ki
+//    sort block are ordered by (hash, position) once per hash kind, so a position's chain is the part of its bucket below its
+//    own slot plus the previous block's bucket.  A wave takes 64 chain nodes per step and replays the chain walk (first-hash
+//    chain, the switch to the second chain, the 8192-hit cap, the quick reject, the stop at `limit`) with ballots and a prefix
+//    maximum.  The result of every search — the (length, distance) change points of `sublen` — is stored once per input
+//    position ("match table") and shared by every block-splitting option and squeeze iteration; Zopfli's longest-match cache
+//    memoises the same function per block.  Positions whose result depends on where their block ends (the last 258 bytes, or
+//    a byte run that crosses the end) are searched again per block ("tail tables") by a window scan that keeps the keys of
+//    the 32 Ki positions before a tile in LDS and applies the block's end to the run lengths on the fly.
 //  * The squeeze (iterated shortest path) runs one wave per block with the cost window and the chosen lengths in LDS
 //    rings; lanes relax the 3..258 match lengths of a position together.  Costs are the same IEEE doubles / floats in
 //    the same order as the CPU code; log() is zopf_portable_log restated (+,-,*,/ only, no contraction).
