@@ -280,14 +280,14 @@ def test_zopfli_encoder_in_the_emulator(sim):
         ZF.lib().zopf_match_table(data, 0, e, ol.ctypes.data, od.ctypes.data, None)
         assert np.array_equal(l16[:e], np.where(ol >= 3, ol, 0)) and np.array_equal(d16[:e], np.where(ol >= 3, od, 0))
     text = zlib.decompress(rd("asyoulik_asyoulik-gzip.s00.in.deflate"), -15)
-    mix = text[:220] + bytes(rng.randrange(256) for _ in range(120)) + bytes(560) + text[3000:3100]
+    mix = text[:150] + bytes(rng.randrange(256) for _ in range(80)) + bytes(540) + text[3000:3070]
     for split in (ZF.SPLIT_FIRST, ZF.SPLIT_LAST, ZF.SPLIT_NONE):
         datas = [mix, b"", b"hello hello hello hello", synth.reptext(500, 9)] if split == ZF.SPLIT_FIRST else [mix]
         outs = D.zopfli_streams(datas, 3, split, 15, 8 << 20, lib=L)
         for d, o in zip(datas, outs):
             assert o == ZF.deflate(d, 3, split, 15, 8 << 20, ZF.LOG_PORTABLE), (len(d), split)
     assert D.zopfli_streams([mix], 2, ZF.SPLIT_FIRST, 0, 400, lib=L)[0] == ZF.deflate(mix, 2, ZF.SPLIT_FIRST, 0, 400, ZF.LOG_PORTABLE)
-    data = [text[:160], b""]
+    data = [text[:110], b""]
     for mode in (D.MODE_ZOPFLI, D.MODE_ZOPFLI_VERY_EXTENSIVE):
         cu = D.CompressionUtil(mode, 2, True, lib=L)
         for d, o, w in zip(data, cu.compress_many(data), cu.last_winner):
