@@ -584,10 +584,9 @@ struct ZfEvalLds {
     uint32_t llc2[ZF_NUM_LL], dc2[ZF_NUM_D];    // the RLE-smoothed copies
     uint8_t good[ZF_NUM_LL], goodD[ZF_NUM_D];
     uint8_t ll[ZF_NUM_LL], d[ZF_NUM_D], ll2[ZF_NUM_LL], d2[ZF_NUM_D];
-    int32_t m[4];
-    int32_t lvl[4][16];
+    int32_t lvl[2][16];
     union {
-        struct { ZfPmBig big[2]; ZfPmSmall small[2]; } pm;
+        struct { ZfPmBig big[1]; ZfPmSmall small[1]; } pm;
         ZfClInst cl[16];
         uint16_t chunk[4096];                    // the squeeze's trace window
     } u;
@@ -766,19 +765,20 @@ D4G_DEV long long zf_dynamic_lengths(ZfEvalLds& E, int* combo) {
     if (lane == 2) zf_optimize_rle(ZF_NUM_LL, E.llc2, E.good);
     if (lane == 3) zf_optimize_rle(ZF_NUM_D, E.dc2, E.goodD);
     LZ_WAVE_SYNC();
-    const int m0 = zf_sort_leaves(E.llc, ZF_NUM_LL, E.u.pm.big[0].w, E.u.pm.big[0].sym);
-    const int m1 = zf_sort_leaves(E.dc, ZF_NUM_D, E.u.pm.small[0].w, E.u.pm.small[0].sym);
-    const int m2 = zf_sort_leaves(E.llc2, ZF_NUM_LL, E.u.pm.big[1].w, E.u.pm.big[1].sym);
-    const int m3 = zf_sort_leaves(E.dc2, ZF_NUM_D, E.u.pm.small[1].w, E.u.pm.small[1].sym);
-    LZ_WAVE_SYNC();
-    if (lane < 4) {
-        ZfPmRef r;
-        uint8_t* out;
-        if (lane == 0) { r = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, m0, E.lvl[0]}; out = E.ll; }
-        else if (lane == 1) { r = {E.u.pm.small[0].w, E.u.pm.small[0].sym, E.u.pm.small[0].list[0], E.u.pm.small[0].list[1], &E.u.pm.small[0].bits[0][0], 2, m1, E.lvl[1]}; out = E.d; }
-        else if (lane == 2) { r = {E.u.pm.big[1].w, E.u.pm.big[1].sym, E.u.pm.big[1].list[0], E.u.pm.big[1].list[1], &E.u.pm.big[1].bits[0][0], 18, m2, E.lvl[2]}; out = E.ll2; }
-        else { r = {E.u.pm.small[1].w, E.u.pm.small[1].sym, E.u.pm.small[1].list[0], E.u.pm.small[1].list[1], &E.u.pm.small[1].bits[0][0], 2, m3, E.lvl[3]}; out = E.d2; }
-        zf_pm_serial(r, 15, out);
+    // two passes over one set of package-merge scratch: the plain counts' trees (lit/len on lane 0, distance on lane 1), then the
+    // smoothed counts' (a second set would let all four run at once, but the scratch is what bounds the waves per CU)
+    for (int pass = 0; pass < 2; pass++) {
+        const int mBig = zf_sort_leaves(pass ? E.llc2 : E.llc, ZF_NUM_LL, E.u.pm.big[0].w, E.u.pm.big[0].sym);
+        const int mSmall = zf_sort_leaves(pass ? E.dc2 : E.dc, ZF_NUM_D, E.u.pm.small[0].w, E.u.pm.small[0].sym);
+        LZ_WAVE_SYNC();
+        if (lane < 2) {
+            ZfPmRef r;
+            uint8_t* out;
+            if (lane == 0) { r = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, mBig, E.lvl[0]}; out = pass ? E.ll2 : E.ll; }
+            else { r = {E.u.pm.small[0].w, E.u.pm.small[0].sym, E.u.pm.small[0].list[0], E.u.pm.small[0].list[1], &E.u.pm.small[0].bits[0][0], 2, mSmall, E.lvl[1]}; out = pass ? E.d2 : E.d; }
+            zf_pm_serial(r, 15, out);
+        }
+        LZ_WAVE_SYNC();
     }
     LZ_WAVE_SYNC();
     if (lane == 0) zf_patch_dist(E.d);
