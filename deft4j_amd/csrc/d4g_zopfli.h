@@ -18,7 +18,7 @@
 //    rings; lanes relax the 3..258 match lengths of a position together.  Costs are the same IEEE doubles / floats in
 //    the same order as the CPU code; log() is zopf_portable_log restated (+,-,*,/ only, no contraction).
 //  * Length-limited code lengths come from a level-by-level package-merge whose ties break as Zopfli's boundary
-//    package-merge does (a package before a leaf of equal weight); four trees of one evaluation run on four lanes.
+//    package-merge does (a package before a leaf of equal weight); the trees of one evaluation run two at a time on two lanes.
 //  * Block splitting evaluates the nine probes of a round from ten segment histograms counted in one sweep.
 #pragma once
 #include "d4g_device.h"
