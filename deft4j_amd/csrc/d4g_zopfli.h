@@ -18,7 +18,7 @@
 //    rings; lanes relax the 3..258 match lengths of a position together.  Costs are the same IEEE doubles / floats in
 //    the same order as the CPU code; log() is zopf_portable_log restated (+,-,*,/ only, no contraction).
 //  * Length-limited code lengths come from a level-by-level package-merge whose ties break as Zopfli's boundary
-//    package-merge does (a package before a leaf of equal weight); the trees of one evaluation run two at a time on two lanes.
+//    package-merge does (a package before a leaf of equal weight); on the GPU every level is merged by the whole wave with binary searches.
 //  * Block splitting evaluates the nine probes of a round from ten segment histograms counted in one sweep.
 #pragma once
 #include "d4g_device.h"
@@ -656,6 +656,65 @@ D4G_DEV void zf_pm_serial(const ZfPmRef& r, int maxbits, uint8_t* out) {
         out[r.sym[q]] = (uint8_t)len;
     }
 }
+// The same package-merge by a whole wave: a level's merged order comes from two binary searches per item (a leaf goes behind
+// the pairs that weigh at most as much, a pair behind the leaves that weigh strictly less), the leaf bits are OR-ed into the
+// level's mask, and the top-down pass counts mask prefixes with popcounts.  All 64 lanes call it with the same arguments.
+D4G_DEV void zf_pm_wave(const ZfPmRef& r, int maxbits, uint8_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int m = r.m;
+    if (m == 0) return;
+    if (m <= 2) { if (lane < m) out[r.sym[lane]] = 1; LZ_WAVE_SYNC(); return; }
+    const int mb = maxbits < m - 1 ? maxbits : m - 1;
+    uint32_t* prev = r.list0;
+    uint32_t* cur = r.list1;
+    for (int i = lane; i < m; i += 64) prev[i] = r.w[i];
+    int lenPrev = m;
+    LZ_WAVE_SYNC();
+    for (int l = 1; l < mb; l++) {
+        uint32_t* bits = r.bits + l * r.stride;
+        for (int k = lane; k < r.stride; k += 64) bits[k] = 0;
+        LZ_WAVE_SYNC();
+        const int np = lenPrev >> 1;
+        for (int i = lane; i < m; i += 64) {
+            const uint32_t x = r.w[i];
+            int lo = 0, hi = np;                       // first pair heavier than the leaf
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (prev[2 * mid] + prev[2 * mid + 1] <= x) lo = mid + 1; else hi = mid; }
+            const int pos = i + lo;
+            cur[pos] = x;
+            atomicOr(&bits[pos >> 5], 1u << (pos & 31));
+        }
+        for (int k = lane; k < np; k += 64) {
+            const uint32_t x = prev[2 * k] + prev[2 * k + 1];
+            int lo = 0, hi = m;                        // first leaf at least as heavy as the pair
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (r.w[mid] < x) lo = mid + 1; else hi = mid; }
+            cur[k + lo] = x;
+        }
+        lenPrev = m + np;
+        uint32_t* t = prev; prev = cur; cur = t;
+        LZ_WAVE_SYNC();
+    }
+    int t = 2 * m - 2;
+    for (int l = mb - 1; l >= 1; l--) {
+        const uint32_t* bits = r.bits + l * r.stride;
+        int part = 0;
+        for (int k = lane; k * 32 < t; k += 64) {
+            uint32_t wd = bits[k];
+            if (t - k * 32 < 32) wd &= (1u << (t - k * 32)) - 1u;
+            part += __popcll((unsigned long long)wd);
+        }
+        const int a = wave_sum_i32(part);
+        if (lane == 0) r.lvl[l] = a;
+        t = 2 * (t - a);
+    }
+    if (lane == 0) r.lvl[0] = t;
+    LZ_WAVE_SYNC();
+    for (int q = lane; q < m; q += 64) {
+        int len = 0;
+        for (int l = 0; l < mb; l++) len += r.lvl[l] > q ? 1 : 0;
+        out[r.sym[q]] = (uint8_t)len;
+    }
+    LZ_WAVE_SYNC();
+}
 D4G_DEV void zf_patch_dist(uint8_t* d) {   // PatchDistanceCodesForBuggyDecoders
     int num = 0;
     for (int i = 0; i < 30; i++) { if (d[i]) num++; if (num >= 2) return; }
@@ -771,6 +830,9 @@ D4G_DEV long long zf_dynamic_lengths(ZfEvalLds& E, int* combo) {
         const int mBig = zf_sort_leaves(pass ? E.llc2 : E.llc, ZF_NUM_LL, E.u.pm.big[0].w, E.u.pm.big[0].sym);
         const int mSmall = zf_sort_leaves(pass ? E.dc2 : E.dc, ZF_NUM_D, E.u.pm.small[0].w, E.u.pm.small[0].sym);
         LZ_WAVE_SYNC();
+#ifdef D4G_HOSTSIM
+        // (the CPU emulation keeps its test time down with the one-lane builder here; the wave-wide one is compared with the oracle
+        // through d4g_debug_zopfli_code_lengths in the same test, and on the GPU every stream is)
         if (lane < 2) {
             ZfPmRef r;
             uint8_t* out;
@@ -778,6 +840,14 @@ D4G_DEV long long zf_dynamic_lengths(ZfEvalLds& E, int* combo) {
             else { r = {E.u.pm.small[0].w, E.u.pm.small[0].sym, E.u.pm.small[0].list[0], E.u.pm.small[0].list[1], &E.u.pm.small[0].bits[0][0], 2, mSmall, E.lvl[1]}; out = pass ? E.d2 : E.d; }
             zf_pm_serial(r, 15, out);
         }
+#else
+        {
+            ZfPmRef rb = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, mBig, E.lvl[0]};
+            ZfPmRef rs = {E.u.pm.small[0].w, E.u.pm.small[0].sym, E.u.pm.small[0].list[0], E.u.pm.small[0].list[1], &E.u.pm.small[0].bits[0][0], 2, mSmall, E.lvl[1]};
+            zf_pm_wave(rb, 15, pass ? E.ll2 : E.ll);
+            zf_pm_wave(rs, 15, pass ? E.d2 : E.d);
+        }
+#endif
         LZ_WAVE_SYNC();
     }
     LZ_WAVE_SYNC();

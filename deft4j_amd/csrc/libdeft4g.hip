@@ -484,9 +484,9 @@ __global__ void __launch_bounds__(64) k_zf_debug_code_lengths(const uint32_t* fr
     LZ_WAVE_SYNC();
     const int m = zf_sort_leaves(E.llc, n, E.u.pm.big[0].w, E.u.pm.big[0].sym);
     LZ_WAVE_SYNC();
-    if (lane == 0) {
+    {   // the wave-wide builder (what the GPU's block-size evaluation uses for the lit/len and distance trees)
         ZfPmRef r = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, m, E.lvl[0]};
-        zf_pm_serial(r, maxbits, E.ll);
+        zf_pm_wave(r, maxbits, E.ll);
     }
     LZ_WAVE_SYNC();
     for (int i = lane; i < n; i += 64) out[i] = E.ll[i];
