@@ -593,20 +593,35 @@ struct ZfEvalLds {
 };
 struct ZfPmRef { uint32_t* w; uint16_t* sym; uint32_t* list0; uint32_t* list1; uint32_t* bits; int stride; int m; int32_t* lvl; };
 
-// sorted leaves (weight, then symbol) of the non-zero counts; all lanes of the wave
-D4G_DEV int zf_sort_leaves(const uint32_t* counts, int n, uint32_t* w, uint16_t* sym) {
+// sorted leaves (weight, then symbol) of the non-zero counts; all lanes of the wave.  The used symbols are compacted first
+// (tmp: 2 n words), so the rank of each costs one pass over the used symbols, not over the alphabet.
+D4G_DEV int zf_sort_leaves(const uint32_t* counts, int n, uint32_t* w, uint16_t* sym, uint32_t* tmp) {
     const int lane = threadIdx.x & 63;
+    uint32_t* tc = tmp;
+    uint32_t* ti = tmp + n;
     int nz = 0;
-    for (int i = lane; i < n; i += 64) {
-        const uint32_t c = counts[i];
-        if (!c) continue;
-        nz++;
-        int rank = 0;
-        for (int j = 0; j < n; j++) { const uint32_t cj = counts[j]; rank += (cj != 0 && (cj < c || (cj == c && j < i))) ? 1 : 0; }
-        w[rank] = c;
-        sym[rank] = (uint16_t)i;
+    LZ_WAVE_SYNC();
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t c = i < n ? counts[i] : 0u;
+        const unsigned long long m = __ballot(c != 0u);
+        if (c) {
+            const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
+            tc[pos] = c;
+            ti[pos] = (uint32_t)i;
+        }
+        nz += __popcll(m);
     }
-    return wave_sum_i32(nz);
+    LZ_WAVE_SYNC();
+    for (int p = lane; p < nz; p += 64) {
+        const uint32_t c = tc[p];
+        int rank = 0;
+        for (int q = 0; q < nz; q++) { const uint32_t cq = tc[q]; rank += (cq < c || (cq == c && q < p)) ? 1 : 0; }
+        w[rank] = c;
+        sym[rank] = (uint16_t)ti[p];
+    }
+    LZ_WAVE_SYNC();
+    return nz;
 }
 // Package-merge, one lane: level l's list = leaves merged with the pairs of level l-1's list, a pair before a leaf of
 // equal weight (BoundaryPM's `sum > leaf weight` test); the code length of the r-th lightest leaf = the number of
@@ -827,8 +842,8 @@ D4G_DEV long long zf_dynamic_lengths(ZfEvalLds& E, int* combo) {
     // two passes over one set of package-merge scratch: the plain counts' trees (lit/len on lane 0, distance on lane 1), then the
     // smoothed counts' (a second set would let all four run at once, but the scratch is what bounds the waves per CU)
     for (int pass = 0; pass < 2; pass++) {
-        const int mBig = zf_sort_leaves(pass ? E.llc2 : E.llc, ZF_NUM_LL, E.u.pm.big[0].w, E.u.pm.big[0].sym);
-        const int mSmall = zf_sort_leaves(pass ? E.dc2 : E.dc, ZF_NUM_D, E.u.pm.small[0].w, E.u.pm.small[0].sym);
+        const int mBig = zf_sort_leaves(pass ? E.llc2 : E.llc, ZF_NUM_LL, E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[1]);
+        const int mSmall = zf_sort_leaves(pass ? E.dc2 : E.dc, ZF_NUM_D, E.u.pm.small[0].w, E.u.pm.small[0].sym, E.u.pm.small[0].list[1]);
         LZ_WAVE_SYNC();
 #ifdef D4G_HOSTSIM
         // (the CPU emulation keeps its test time down with the one-lane builder here; the wave-wide one is compared with the oracle

@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64) k_zf_debug_code_lengths(const uint32_t* fr
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < ZF_NUM_LL; i += 64) { E.llc[i] = i < n ? freq[i] : 0; E.ll[i] = 0; }
     LZ_WAVE_SYNC();
-    const int m = zf_sort_leaves(E.llc, n, E.u.pm.big[0].w, E.u.pm.big[0].sym);
+    const int m = zf_sort_leaves(E.llc, n, E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[1]);
     LZ_WAVE_SYNC();
     {   // the wave-wide builder (what the GPU's block-size evaluation uses for the lit/len and distance trees)
         ZfPmRef r = {E.u.pm.big[0].w, E.u.pm.big[0].sym, E.u.pm.big[0].list[0], E.u.pm.big[0].list[1], &E.u.pm.big[0].bits[0][0], 18, m, E.lvl[0]};
