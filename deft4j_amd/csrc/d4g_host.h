@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "d4g_ops.h"
+#include "d4g_fused.h"
 #include "d4g_parse.h"
 #include "d4g_rt.h"
 #include "d4g_write.h"
@@ -66,6 +67,16 @@ static inline int lanes() {
 // launch per program level over all active blocks — wins once there are enough blocks to fill the chip
 // (config 2, 332 blocks: 79 vs 87 ms).  D4G_EXEC=persistent|levels forces one; default switches at
 // D4G_PERSIST_MAX_BLOCKS active blocks.
+// "fused" (the default): one workgroup per block runs the whole search, all rounds, out of LDS (d4g_fused.h); the two
+// executors below remain for blocks it does not take (very large merged blocks, table overflows) and as cross-checks.
+static inline bool exec_fused() {
+    const char* t = getenv("D4G_EXEC");
+    return !t || !strcmp(t, "fused");
+}
+static inline long long fused_max_refs() {   // blocks with more back-references than this go to the level / persistent executors
+    const char* t = getenv("D4G_FUSED_MAX_REFS");
+    return t ? atoll(t) : (1LL << 17);
+}
 static inline int exec_persistent(int nActive = 0) {
     // read per call (not cached): the parity tests switch executors inside one process
     const char* t = getenv("D4G_EXEC");
@@ -306,6 +317,15 @@ struct Program {
             ops.swap(kept);
             opLevel.swap(keptLevel);
         }
+        // optimise() results nothing builds on (they are offered / searched for headers only): the fused executor computes
+        // their size without writing their tokens down (arg bit 8; the other executors read bit 0 only)
+        {
+            std::vector<int> stateUses(nSlots, 0);
+            for (const D4GOp& o : ops)
+                if (o.kind != OP_HDRSEARCH && o.kind != OP_CAND) stateUses[o.src]++;
+            for (D4GOp& o : ops)
+                if (o.kind == OP_OPT && stateUses[o.dst] == 0) o.arg |= 0x100;
+        }
         nLevels = 0;
         for (int l : opLevel) nLevels = std::max(nLevels, l + 1);
         stateLevels.assign(nLevels, {});
@@ -466,6 +486,9 @@ struct Engine {  // per-process device objects shared by all batches
         rt_sync();
         slotsPerBlock = std::max(progDyn.nSlots, progFixed.nSlots);
         masksPerBlock = std::max(progDyn.nMasks, progFixed.nMasks);
+        // the fused executor carves its per-block tables out of the same pools (d4g_fused.h: d4f_glob, d4f_eset)
+        slotsPerBlock = std::max<int>(slotsPerBlock, 2 + (int)((D4F_GLOB_BYTES + sizeof(D4GState) - 1) / sizeof(D4GState)));
+        masksPerBlock = std::max<int>(masksPerBlock, D4F_MAXM + 2 * D4F_MAXC);
         maxOps = (int)std::max(progDyn.ops.size(), progFixed.ops.size());
         if ((i64)maxOps * 64 >= (1LL << D4G_KEY_SEQ_BITS)) throw std::runtime_error("program too long for the key layout");
         ready = true;
@@ -978,7 +1001,108 @@ struct Batch {
     // One optimiseBlock call on every block of `act` (device block indices): runs the program
     // matching each block's current type and returns the per-block results in `act` order.
     double msSearch = 0;
+    // One optimiseBlock call per block of `act`: the fused executor takes the blocks it can hold, the level / persistent
+    // executors the rest.
     std::vector<D4GRoundResult> run_round(const std::vector<int>& act) {
+        if (!exec_fused()) return run_round_legacy(act);
+        std::vector<D4GRoundResult> res(act.size());
+        std::vector<int> small, big;
+        std::vector<size_t> smallPos, bigPos;
+        for (size_t i = 0; i < act.size(); i++) {
+            if (hBlocks[act[i]].refCount <= fused_max_refs()) { small.push_back(act[i]); smallPos.push_back(i); }
+            else { big.push_back(act[i]); bigPos.push_back(i); }
+        }
+        if (!small.empty()) {
+            std::vector<std::vector<D4GRoundResult>> ch = run_fused(small, 1);
+            for (size_t i = 0; i < small.size(); i++) res[smallPos[i]] = ch[i].at(0);
+        }
+        if (!big.empty()) {
+            std::vector<D4GRoundResult> r = run_round_legacy(big);
+            for (size_t i = 0; i < big.size(); i++) res[bigPos[i]] = r[i];
+        } else {
+            stats.rounds++;
+        }
+        return res;
+    }
+    // Fused executor (k_search_fused): every block of `act` runs up to maxRounds optimiseBlock rounds, while it keeps
+    // improving, inside one workgroup.  Returns each block's chain of round results.  A round that does not fit the
+    // kernel's tables comes back untouched and is run by the level executor; the block then goes on here.
+    std::vector<std::vector<D4GRoundResult>> run_fused(const std::vector<int>& act, int maxRounds) {
+        Engine& E = engine();
+        std::vector<std::vector<D4GRoundResult>> chains(act.size());
+        std::vector<int> todo(act.size());
+        for (size_t i = 0; i < act.size(); i++) todo[i] = (int)i;
+        D4GRoundResult* dRes = nullptr;
+        int32_t* dInfo = nullptr;
+        while (!todo.empty()) {
+            const int nA = (int)todo.size();
+            std::vector<int32_t> sub(nA);
+            for (int i = 0; i < nA; i++) sub[i] = act[todo[i]];
+            rt().cur = 0;
+            rt_h2d(dActive, sub.data(), sub.size() * sizeof(int32_t));
+            if (!dRes) {
+                dRes = (D4GRoundResult*)rt_malloc(act.size() * (size_t)D4F_MAXROUNDS * sizeof(D4GRoundResult));
+                dInfo = (int32_t*)rt_malloc(act.size() * sizeof(int32_t) + 16);
+            }
+            D4GCtx c = make_ctx(E.progDyn, nA);
+            D4FParams P;
+            memset(&P, 0, sizeof(P));
+            P.ops[0] = E.progDyn.dOps; P.ops[1] = E.progFixed.dOps;
+            P.nOps[0] = (int)E.progDyn.ops.size(); P.nOps[1] = (int)E.progFixed.ops.size();
+            P.results = dRes;
+            P.roundInfo = dInfo;
+            P.stats = getenv("D4G_FUSED_STATS") ? E.dOpStats : nullptr;
+            std::vector<int> left(nA);
+            int cap = 0;
+            for (int i = 0; i < nA; i++) { left[i] = maxRounds - (int)chains[todo[i]].size(); cap = std::max(cap, left[i]); }
+            P.maxRounds = std::min(cap, (int)D4F_MAXROUNDS);
+            RtEvent e0, e1;
+            e0.record();
+#ifdef D4G_HOSTSIM
+            const int fusedBlock = std::max(128, state_block());
+#else
+            static const int fusedBlock = env_int("D4G_FUSED_BLOCK", 512);
+#endif
+            RT_LAUNCH(k_search_fused, nA, fusedBlock, c, P);
+            e1.record();
+            stats.kernel_launches++;
+            stats.state_launches++;
+            std::vector<int32_t> info(nA);
+            rt_d2h(info.data(), dInfo, (size_t)nA * sizeof(int32_t));
+            std::vector<D4GRoundResult> r((size_t)nA * D4F_MAXROUNDS);
+            rt_d2h(r.data(), dRes, r.size() * sizeof(D4GRoundResult));
+            const float ms = rt_elapsed_ms(e0, e1);
+            msSearch += ms;
+            stats.ms_state_kernels += ms;
+            for (int k : sub) { stats.state_tokens_per_round += hBlocks[k].tokCount; stats.state_bytes_per_round += hBlocks[k].uLen; }
+            if (getenv("D4G_DEBUG_ROUNDS")) fprintf(stderr, "fused search: %d blocks, up to %d rounds, %.3f ms\n", nA, P.maxRounds, ms);
+            std::vector<int> next, fb;
+            for (int i = 0; i < nA; i++) {
+                const int n = info[i] & 0xffff;
+                std::vector<D4GRoundResult>& ch = chains[todo[i]];
+                for (int k = 0; k < n; k++) ch.push_back(r[(size_t)i * D4F_MAXROUNDS + k]);
+                if (n) gpuType[sub[i]] = ch.back().newType;
+                stats.rounds_fused += n;
+                if (info[i] & D4F_INFO_FALLBACK) fb.push_back(todo[i]);
+                else if ((info[i] & D4F_INFO_MORE) && (int)ch.size() < maxRounds) next.push_back(todo[i]);
+            }
+            if (!fb.empty()) {   // one round with the level executor, then back here if it improved
+                std::vector<int> fbAct(fb.size());
+                for (size_t i = 0; i < fb.size(); i++) fbAct[i] = act[fb[i]];
+                std::vector<D4GRoundResult> rr = run_round_legacy(fbAct);
+                stats.fused_fallbacks += (int64_t)fb.size();
+                for (size_t i = 0; i < fb.size(); i++) {
+                    chains[fb[i]].push_back(rr[i]);
+                    if (rr[i].improved && (int)chains[fb[i]].size() < maxRounds) next.push_back(fb[i]);
+                }
+            }
+            std::sort(next.begin(), next.end());
+            todo.swap(next);
+        }
+        rt_free(dRes); rt_free(dInfo);
+        return chains;
+    }
+    std::vector<D4GRoundResult> run_round_legacy(const std::vector<int>& act) {
         Engine& E = engine();
         std::vector<D4GRoundResult> res(act.size());
         for (int pass = 0; pass < 2; pass++) {
@@ -1164,9 +1288,24 @@ struct Batch {
                 if (b.type != D4G_STORED) { act.push_back(b.gpu); owner.push_back({(int)si, (int)k}); }
             }
         }
+        if (exec_fused()) {   // all rounds of a block inside one workgroup; blocks the fused executor does not take follow below
+            std::vector<int> fa, rest;
+            std::vector<std::pair<int, int>> fo, ro;
+            for (size_t i = 0; i < act.size(); i++) {
+                if (hBlocks[act[i]].refCount <= fused_max_refs()) { fa.push_back(act[i]); fo.push_back(owner[i]); }
+                else { rest.push_back(act[i]); ro.push_back(owner[i]); }
+            }
+            if (!fa.empty()) {
+                std::vector<std::vector<D4GRoundResult>> ch = run_fused(fa, 1 << 20);
+                for (size_t i = 0; i < fa.size(); i++) streams[fo[i].first].blocks[fo[i].second].chain = ch[i];
+                stats.rounds++;
+            }
+            act.swap(rest);
+            owner.swap(ro);
+        }
         // fixpoint rounds: every block follows its own chain of strictly improving Huffman states
         while (!act.empty()) {
-            std::vector<D4GRoundResult> res = run_round(act);
+            std::vector<D4GRoundResult> res = run_round_legacy(act);
             std::vector<int> nact;
             std::vector<std::pair<int, int>> nowner;
             for (size_t i = 0; i < act.size(); i++) {

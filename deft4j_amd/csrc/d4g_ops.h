@@ -1523,7 +1523,7 @@ struct D4GHdrLds {
     uint8_t cl1[19 * 64];
 };
 
-__device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits, long long* prof = nullptr) {
+__device__ __forceinline__ long long d4g_hdr_candidate_body(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits, long long* prof = nullptr) {
 #ifdef D4G_PROFILE_OPS
     long long q0 = d4g_clock_drained();
 #endif
@@ -1632,6 +1632,10 @@ __device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int pr
 #undef C0
 #undef C1
     return litlenBits + hdr;
+}
+// (a call in the header-search kernels; the fused executor inlines the body under its own register budget)
+__device__ long long d4g_hdr_candidate(D4GHdrLds* H, int lane, int flags, int prune, long long litlenBits, long long* prof = nullptr) {
+    return d4g_hdr_candidate_body(H, lane, flags, prune, litlenBits, prof);
 }
 
 __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c, int blk, int opId) {

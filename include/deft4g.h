@@ -66,6 +66,8 @@ typedef struct d4g_stats {
      * and the block choice + emission; squeeze work = sum over blocks of iterations x block bytes */
     double ms_zopfli_table, ms_zopfli_split, ms_zopfli_squeeze, ms_zopfli_emit;
     int64_t zopfli_blocks, zopfli_position_iterations;
+    /* fused executor (one workgroup per block, all rounds): optimiseBlock rounds it ran, rounds handed to the level executor */
+    int64_t rounds_fused, fused_fallbacks;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

@@ -5,7 +5,7 @@ paths the benchmark workload never takes: > 64 used literal symbols (queue slots
 frequencies (trees deeper than 15 / 7 -> the reference's depth limiter), stored / fixed / empty blocks from flushes,
 HUFFMAN_ONLY and RLE strategies, long runs (len-258 matches), tiny blocks.
 
-usage: gpu_fuzz.py [seconds] [seed] [--big]"""
+usage: gpu_fuzz.py [seconds] [seed] [--big] [--sim]   (--sim: the CPU emulation of the kernels, tests/hostsim — small inputs)"""
 import os, random, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,8 +13,13 @@ import deft4j_amd as D, oracle_lib as O, synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 BIG = "--big" in sys.argv   # also 1-3 MiB inputs (many blocks, several merge chains)
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-D.init(0)
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 12345)
+SIM = "--sim" in sys.argv
+LIB = None
+if SIM:
+    os.environ.setdefault("D4G_SIM_BLOCK", "64")
+    LIB = D.load_library(os.path.join(ROOT, "tests", "hostsim", "libdeft4g_hostsim.so"))
+D.init(0, lib=LIB)
 
 
 def fib_bytes(n):
@@ -28,7 +33,7 @@ def fib_bytes(n):
 
 def gen():
     kind = rng.randrange(9)
-    n = rng.choice([0, 1, 2, 50, 300, 3000, 20000, 70000, 200000] + ([1 << 19, 1 << 20] if BIG else []))
+    n = rng.choice([0, 1, 2, 50, 300, 3000, 20000] + ([] if SIM else [70000, 200000]) + ([1 << 19, 1 << 20] if BIG else []))
     if kind == 0: raw = synth.reptext(n, rng.randrange(1 << 30))
     elif kind == 1: raw = bytes(rng.randrange(256) for _ in range(min(n, 30000)))
     elif kind == 2: raw = fib_bytes(n)
@@ -52,10 +57,10 @@ def gen():
 
 t0 = time.time(); nstreams = 0; nbytes = 0; it = 0
 while time.time() - t0 < budget:
-    batch = [gen() for _ in range(rng.randrange(1, 6 if BIG else 24))]
+    batch = [gen() for _ in range(rng.randrange(1, 6 if BIG or SIM else 24))]
     ins = [b[0] for b in batch]
     for merge in (False, True):
-        bt = D.Batch(ins).run(merge)
+        bt = D.Batch(ins, lib=LIB).run(merge)
         for i, (a, raw) in enumerate(batch):
             if BIG: print("  oracle: stream %d (%d bytes) merge %s" % (i, len(a), merge), flush=True)
             rc, want, saved, consumed, _ = O.optimise(a, merge)

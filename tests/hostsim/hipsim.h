@@ -103,6 +103,11 @@ inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long ex
     if (o == expect) *p = v;
     return o;
 }
+inline unsigned atomicCAS(unsigned* p, unsigned expect, unsigned v) {
+    unsigned o = *p;
+    if (o == expect) *p = v;
+    return o;
+}
 inline void __threadfence() {}
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }

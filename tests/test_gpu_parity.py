@@ -42,7 +42,7 @@ def test_all_reference_fixture_pairs_bit_exact(D):
         b.close()
 
 
-@pytest.mark.parametrize("mode", ["levels", "persistent"])
+@pytest.mark.parametrize("mode", ["levels", "persistent", "fused"])
 def test_fixture_pairs_under_each_executor(D, monkeypatch, mode):
     """The candidate search has two executors (d4g_host.h exec_persistent): `persistent` work-queue kernels (default at
     <= 128 active blocks) and one launch per program level (`levels`, the one bench.py's 332-block stream runs).

@@ -64,7 +64,7 @@ def test_one_shot_abi_entry_points_in_the_emulator(sim):
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["levels", "persistent"])
+@pytest.mark.parametrize("mode", ["levels", "persistent", "fused"])
 def test_batch_of_synthetic_streams_matches_oracle(sim, monkeypatch, mode):
     monkeypatch.setenv("D4G_EXEC", mode)
     D, L = sim
