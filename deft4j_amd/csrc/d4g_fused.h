@@ -40,7 +40,8 @@
 #define D4F_SWEEP_K 8     // codes evaluated per sweep over the records
 #define D4F_CODE_FIXED 1  // reserved code id: the fixed Huffman code
 #define D4F_MAXROUNDS 16
-#define D4F_TREE_SLOTS 3   // Huffman rebuilds running side by side (one wave each): LDS bounds it
+#define D4F_HS_SLOTS 3      // header searches running side by side (one wave each)
+#define D4F_TREE_SLOTS 4   // Huffman rebuilds running side by side (two waves each: literal/length and distance tree)
 
 #ifdef D4G_HOSTSIM
 D4G_DEV void d4f_fence_block() {}
@@ -121,8 +122,11 @@ D4G_DEV int d4f_qoff(int q) {
 enum { D4F_H_OPT = 1, D4F_H_POST = 2, D4F_H_PRUNE = 3 };
 
 // scratch of one Huffman-rebuild task (one wave): the three trees are built one after the other in the same memory
+typedef TreeMem<uint64_t, uint16_t, D4G_NLIT, 16, true> D4FLitTree;    // (depth scratch of the limiter path overlays the queue)
+typedef TreeMem<uint64_t, uint16_t, D4G_NDIST, 16, true> D4FDistTree;
 struct D4FTreeScr {
-    alignas(16) unsigned char tree[TreeMem<uint64_t, uint16_t, D4G_NLIT>::bytes(1) + 10];
+    alignas(16) unsigned char tree[(D4FLitTree::bytes(1) + 15) & ~15];       // literal/length tree, then the code-length tree
+    alignas(16) unsigned char treeD[(D4FDistTree::bytes(1) + 15) & ~15];     // distance tree (built beside the literal/length tree)
     uint32_t hist[D4G_HIST];
     alignas(16) uint8_t lens[D4G_NLIT + D4G_NDIST];
     uint16_t pairs[D4G_MAXPAIRS];
@@ -161,7 +165,6 @@ union D4FScratch {
     D4FTreeScr tree[D4F_TREE_SLOTS];
     D4FWaveScr wave[8];
     D4FSweepScr sweep;
-    D4FHsScr hs[2];
     D4GLds legacy;           // assembling the winner (the level executor's header functions)
 };
 static_assert(sizeof(D4FHdrScr) <= sizeof(D4FWaveScr), "header scratch overlays the wave scratch");
@@ -171,15 +174,13 @@ struct D4FLds {
     uint8_t slotReady[D4F_MAXSLOTS];
     uint8_t opStage[D4F_MAXOPS];
     uint16_t opReq[D4F_MAXOPS];
-    D4FPassE pass[D4F_PASSN];
-    D4FLeastE least[D4F_LEASTN];
-    D4FHdrE hdrReq[D4F_HDRN];
     long long treeLit[D4F_MAXM];      // Huffman rebuild of mask id m: literal/length bits under the rebuilt code ...
     uint8_t treeC[D4F_MAXM];          // ... its code id ...
     alignas(4) uint8_t treeSt[D4F_MAXM];         // ... 0 not asked, 1 queued, 2 there
     int32_t hdrBits[D4F_MAXH];
     unsigned long long maskH1[D4F_MAXM], maskH2[D4F_MAXM];   // content hashes of the masks (relative to mask 0)
     int32_t maskPop[D4F_MAXM];        // expanded records
+    uint32_t maskFull[D4F_MAXM];      // length symbols known to have every record expanded (bit per symbol): they take no part in least-expensive pruning
     alignas(4) uint16_t maskHash[512];           // id + 1 by maskH1
     uint16_t maskStep[D4F_MAXM];      // step in which the mask was published (content is compared only with masks of earlier steps: their words are visible)
     unsigned long long codeH[D4F_MAXC];
@@ -197,6 +198,11 @@ struct D4FLds {
     long long fixdotLit;
     long long red[32];
     int32_t misc[32];
+    // The header searches run last in a round, when the three tables below and the scratch are dead: their scratch
+    // (D4F_HS_SLOTS searches side by side) overlays all four.
+    alignas(16) D4FLeastE least[D4F_LEASTN];
+    D4FHdrE hdrReq[D4F_HDRN];
+    D4FPassE pass[D4F_PASSN];
     D4FScratch scr;
     // not cleared between rounds: what the kernel was called with, the block, the round in progress
     D4GCtx c;
@@ -208,6 +214,7 @@ struct D4FLds {
 };
 
 static_assert(sizeof(D4FLds) <= 80 * 1024, "two workgroups per CU: 80 KiB of LDS each");
+static_assert(offsetof(D4FLds, c) - offsetof(D4FLds, least) >= D4F_HS_SLOTS * sizeof(D4FHsScr), "header-search scratch overlay");
 // The workgroup's LDS, at namespace scope: the task functions below are real calls (one register budget each instead of
 // one for the whole kernel) and still address it with LDS instructions.
 __shared__ D4FLds d4fLds;
@@ -242,7 +249,7 @@ D4G_DEV void d4f_push(int q, int v) {
 template <int NREG, typename TM, typename FreqFn, typename OutFn>
 __device__ __forceinline__ int d4f_wave_tree(TM& tm, int numSymbols, int limit, FreqFn freq, OutFn out) {
 #if !defined(D4G_HOSTSIM) || defined(D4G_SIM_WAVE_HEAP)
-    return d4g_build_tree_wave<NREG>(tm, numSymbols, limit, freq, out);
+    return d4g_build_tree_wave64<NREG>(tm, numSymbols, limit, freq, out);
 #else
     int err = 0;
     if ((threadIdx.x & 63) == 0) err = d4g_build_tree(tm, 1, 0, numSymbols, limit, freq, out);
@@ -352,9 +359,8 @@ D4G_DEV void d4f_finish(int dst, int m, int c, int h, int type, int valid, long 
     }
 }
 
-D4F_TASK bool d4f_advance_op(const D4GOp* opp, int opId, long long* bestKeyP) {
+D4F_TASK bool d4f_advance_op(const D4GOp op, int opId, long long* bestKeyP) {
     D4FLds& F = d4fLds;
-    const D4GOp op = *opp;
     long long& bestKey = *bestKeyP;
     int stage = F.opStage[opId];
     if (stage == 255) return false;
@@ -716,6 +722,66 @@ D4G_DEV int d4f_publish_mask(const D4GCtx& c, const D4GBlock& b, const D4FGlob& 
     return mNew;
 }
 
+// Record walk over a selection held in registers: lane L holds the selection words L, L + 64, ... (NW of them).  Calls
+// fn(record) for every selected record, 128 at a time through the wave's LDS queue: the records of a batch are requested
+// together (one round trip), not one mask word after the other.
+#define D4F_NWR 4   // selection words per lane in the register forms: blocks of up to 64 * 4 * 64 = 16384 back-references
+template <typename Fn>
+D4G_DEV void d4f_wave_for_bits(const uint64_t (&d)[D4F_NWR], const uint4* rf, uint32_t* queue /* [128] */, Fn fn) {
+    const int lane = threadIdx.x & 63;
+    int pc = 0;
+#pragma unroll
+    for (int j = 0; j < D4F_NWR; j++) pc += __popcll(d[j]);
+    int incl = pc;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        int o = __shfl_up(incl, dd);
+        if (lane >= dd) incl += o;
+    }
+    const int total = __shfl(incl, 63), off = incl - pc;
+    for (int base = 0; base < total; base += 128) {
+        if (off < base + 128 && off + pc > base) {
+            int o = off;
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) {
+                uint64_t x = d[j];
+                while (x) {
+                    const int bit = __ffsll((long long)x) - 1;
+                    x &= x - 1;
+                    if (o >= base && o < base + 128) queue[o - base] = (uint32_t)((lane + 64 * j) * 64 + bit);
+                    o++;
+                }
+            }
+        }
+        d4g_wave_sync();
+        const int n = total - base < 128 ? total - base : 128;
+        const bool v0 = lane < n, v1 = lane + 64 < n;
+        const uint32_t r0 = v0 ? queue[lane] : 0u, r1 = v1 ? queue[lane + 64] : 0u;
+        uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = make_uint4(0u, 0u, 0u, 0u);
+        if (v0) a0 = rf[r0];
+        if (v1) a1 = rf[r1];
+        if (v0) fn(a0);
+        if (v1) fn(a1);
+        d4g_wave_sync();
+    }
+}
+// the wave's code tables from the code's lengths, words requested by the caller beforehand: w0 = word `lane` of lens, w1 = word 64 + lane (lanes < 16)
+D4G_DEV void d4f_wave_code_from_words(D4FWaveScr& W, uint32_t w0, uint32_t w1) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int l = (int)((w0 >> (8 * j)) & 255u); W.lc[4 * lane + j] = (uint16_t)(l ? l : D4G_NO_CODE); }
+    W.cl[lane] = 0;
+    d4g_wave_sync();
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sidx = 256 + 4 * lane + j, l = (int)((w1 >> (8 * j)) & 255u);
+            if (sidx >= 257 && sidx < 286) W.cl[sidx - 257] = (uint8_t)l;
+            if (sidx >= D4G_NLIT && sidx < D4G_NLIT + 30) W.cl[32 + sidx - D4G_NLIT] = (uint8_t)l;
+        }
+    }
+    d4g_wave_sync();
+}
+
 // ---------------------------------------------------------------------------------------
 // Mask update (one wave per task): replaceBackrefsWithLiteralsIfSmaller of a state (mask m, code) = expand E(code) \ m.
 // leaf: only the bits saved are wanted (the state is offered as a candidate / searched for headers, nothing builds on
@@ -735,6 +801,76 @@ D4F_TASK void d4f_apply_task(int idx) {
     const uint4* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     const uint32_t* Uw = (const uint32_t*)Ub;
+    if (nWords <= 64 * D4F_NWR) {
+        // register form: everything the task reads up front goes out in one round trip (mask and E words, the histogram,
+        // the code's lengths), the selected records in a second one
+        uint64_t ew[D4F_NWR], mw[D4F_NWR], d[D4F_NWR];
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) {
+            const int w = lane + 64 * j;
+            ew[j] = w < nWords ? E[w] : 0ull;
+            mw[j] = w < nWords ? M[w] : 0ull;
+        }
+        uint32_t hr[D4G_HIST / 64];
+        if (!leaf) {
+#pragma unroll
+            for (int i = 0; i < D4G_HIST / 64; i++) hr[i] = G.hist[(size_t)m * D4G_HIST + lane + 64 * i];
+        }
+        const uint32_t* lw = (const uint32_t*)G.code[code].lens;
+        const uint32_t cw0 = lw[lane], cw1 = lane < 16 ? lw[64 + lane] : 0u;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) { d[j] = ew[j] & ~mw[j]; cnt += __popcll(d[j]); }
+        cnt = wave_sum_i32(cnt);
+        if (cnt == 0) {
+            if (lane == 0) { e.mOut = (int16_t)m; e.saved = 0; d4f_fence_block(); e.st = 2; }
+            return;
+        }
+        int mNew = m;
+        if (!leaf) {
+            if (lane == 0) { int id = atomicAdd(&F.nMask, 1); if (id >= D4F_MAXM) { F.fallback = 1; id = 0; } W.misc[0] = id; }
+            d4g_wave_sync();
+            mNew = W.misc[0];
+            d4g_wave_sync();
+            if (mNew == 0) { if (lane == 0) { e.mOut = (int16_t)m; e.saved = 0; d4f_fence_block(); e.st = 2; } return; }
+#pragma unroll
+            for (int i = 0; i < D4G_HIST / 64; i++) W.hist[lane + 64 * i] = hr[i];
+        }
+        d4f_wave_code_from_words(W, cw0, cw1);
+        int savedLane = 0, bad = 0;
+        d4f_wave_for_bits(d, rf, W.queue, [&](const uint4& rv) {
+            const uint32_t a = rv.x;
+            const int cost = W.cl[ref_lsym(a) - 257] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
+            const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
+            const int gain = cost - total;
+            if (gain < (prune ? 0 : 1)) bad = 1;
+            savedLane += gain;
+            if (!leaf) d4f_rec_to_hist(W.hist, Ub, rv);
+        });
+        const int saved = wave_sum_i32(savedLane);
+        if (__ballot(bad) && lane == 0) atomicAdd(c.errors, 1);
+        int mOut = m;
+        if (!leaf) {
+            uint64_t* O = d4f_mask(c, b, mNew);
+            unsigned long long h1 = 0, h2 = 0;
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) {
+                const int w = lane + 64 * j;
+                if (w < nWords) {
+                    const uint64_t o = mw[j], n = o | ew[j];
+                    O[w] = n;
+                    if (n != o) { h1 += d4f_mix1(w, n) - d4f_mix1(w, o); h2 += d4f_mix2(w, n) - d4f_mix2(w, o); }
+                }
+            }
+            h1 = (unsigned long long)wave_sum_i64((long long)h1) + F.maskH1[m];
+            h2 = (unsigned long long)wave_sum_i64((long long)h2) + F.maskH2[m];
+            d4g_wave_sync();
+            if (lane == 0) F.maskFull[mNew] = F.maskFull[m];
+            mOut = d4f_publish_mask(c, b, G, mNew, h1, h2, F.maskPop[m] + cnt, W.hist);
+        }
+        if (lane == 0) { e.mOut = (int16_t)mOut; e.saved = saved; d4f_fence_block(); e.st = 2; }
+        return;
+    }
     int cnt = 0;
     for (int w = lane; w < nWords; w += 64) cnt += __popcll(E[w] & ~M[w]);
     cnt = wave_sum_i32(cnt);
@@ -777,6 +913,7 @@ D4F_TASK void d4f_apply_task(int idx) {
         h1 = (unsigned long long)wave_sum_i64((long long)h1) + F.maskH1[m];
         h2 = (unsigned long long)wave_sum_i64((long long)h2) + F.maskH2[m];
         d4g_wave_sync();
+        if (lane == 0) F.maskFull[mNew] = F.maskFull[m];
         mOut = d4f_publish_mask(c, b, G, mNew, h1, h2, F.maskPop[m] + cnt, W.hist);
     }
     if (lane == 0) { e.mOut = (int16_t)mOut; e.saved = saved; d4f_fence_block(); e.st = 2; }
@@ -832,6 +969,147 @@ D4F_TASK void d4f_least_task(int idx) {
     const uint32_t* Uw = (const uint32_t*)Ub;
     const uint32_t* stat = c.binStat + b.binStat;
     const uint64_t* bmask = c.binMask + b.binMask;
+    if (nWords <= 64 * D4F_NWR) {
+        // register form (see d4f_apply_task).  Length symbols whose records are ALL expanded already (an earlier pruning
+        // step took them) have no unexpanded record, so they are never chosen whatever their sums: their records — often
+        // thousands — are left out of the walk.
+        const uint32_t full = F.maskFull[m];
+        uint64_t mw[D4F_NWR], fw[D4F_NWR], d[D4F_NWR];
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) {
+            const int w = lane + 64 * j;
+            mw[j] = w < nWords ? M[w] : 0ull;
+            fw[j] = 0ull;
+        }
+        for (uint32_t fb = full; fb; fb &= fb - 1) {
+            const uint64_t* fm = bmask + (long long)(__ffs((int)fb) - 1) * nWords;
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) { const int w = lane + 64 * j; if (w < nWords) fw[j] |= fm[w]; }
+        }
+        const uint32_t* lw = (const uint32_t*)G.code[code].lens;
+        const uint32_t cw0 = lw[lane], cw1 = lane < 16 ? lw[64 + lane] : 0u;
+        int bSize = 0, bZ = 0, bCount = 0;
+        if (lane < D4G_NBINS) {
+            bSize = G.binBase[(size_t)code * 64 + lane];
+            bZ = G.binBase[(size_t)code * 64 + 32 + lane];
+            bCount = (int)stat[lane * D4G_BINSTRIDE + D4G_BIN_COUNT];
+        }
+        const bool isFull = lane < D4G_NBINS && ((full >> lane) & 1u);
+        const int popFull = wave_sum_i32(isFull ? bCount : 0);
+        const bool viaExpanded = F.maskPop[m] - popFull <= nRef - F.maskPop[m];   // walk the smaller side
+        if (lane < 32) {
+            W.binSize[lane] = viaExpanded ? bSize : 0;
+            W.binZ[lane] = viaExpanded ? bZ : 0;
+            W.binFreq[lane] = viaExpanded && !isFull ? bCount : 0;
+        }
+        d4f_wave_code_from_words(W, cw0, cw1);
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) {
+            const int w = lane + 64 * j;
+            uint64_t valid = w < nWords ? ~0ull : 0ull;
+            if (w == nWords - 1 && (nRef & 63)) valid = (1ull << (nRef & 63)) - 1;
+            d[j] = viaExpanded ? (mw[j] & ~fw[j]) : (~mw[j] & valid);
+        }
+        if (viaExpanded) {
+            d4f_wave_for_bits(d, rf, W.queue, [&](const uint4& rv) {
+                const uint32_t a = rv.x;
+                const int bin = ref_lsym(a) - 257;
+                const int cost = W.cl[bin] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
+                const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
+                atomicSub(&W.binSize[bin], (total & (D4G_NO_CODE - 1)) - cost);
+                atomicSub(&W.binFreq[bin], 1);
+                if (total >= D4G_NO_CODE) atomicSub(&W.binZ[bin], total >> 14);
+            });
+        } else {
+            d4f_wave_for_bits(d, rf, W.queue, [&](const uint4& rv) {
+                const uint32_t a = rv.x;
+                const int bin = ref_lsym(a) - 257;
+                const int cost = W.cl[bin] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
+                const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
+                atomicAdd(&W.binSize[bin], (total & (D4G_NO_CODE - 1)) - cost);
+                atomicAdd(&W.binFreq[bin], 1);
+                if (total >= D4G_NO_CODE) atomicAdd(&W.binZ[bin], total >> 14);
+            });
+        }
+        d4g_wave_sync();
+        if (lane == 0) {
+            int rem = -1, remSize = 0, remFreq = 0;
+            for (int i = 0; i < D4G_NBINS; i++) {
+                // seen: the bin has an unexpanded record; allowed: none of them holds a byte without a code
+                if (W.binFreq[i] > 0 && W.binZ[i] == 0) {
+                    bool doRem = mode == 1 ? W.binFreq[i] < remFreq : W.binSize[i] < remSize;
+                    if (rem == -1 || doRem) { rem = i; remSize = W.binSize[i]; remFreq = W.binFreq[i]; }
+                }
+            }
+            W.misc[1] = rem; W.misc[2] = remSize;
+            int id = 0;
+            if (rem >= 0) { id = atomicAdd(&F.nMask, 1); if (id >= D4F_MAXM) { F.fallback = 1; id = 0; } }
+            W.misc[0] = id;
+        }
+        d4g_wave_sync();
+        const int rem = W.misc[1], remSize = W.misc[2], mNew = W.misc[0];
+        d4g_wave_sync();
+        if (rem < 0 || mNew == 0) {
+            if (lane == 0) { e.mOut = (int16_t)m; e.delta = 0; d4f_fence_block(); e.st = 2; }
+            return;
+        }
+        // expand the bin: new mask = old | bin mask; the histogram loses the bin's unexpanded records' symbols and gains their bytes
+        const uint64_t* bm = bmask + (long long)rem * nWords;
+        uint64_t bw[D4F_NWR];
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) { const int w = lane + 64 * j; bw[j] = w < nWords ? bm[w] : 0ull; }
+        const uint32_t* row = stat + rem * D4G_BINSTRIDE;
+        uint32_t hr[D4G_HIST / 64], rr[D4G_HIST / 64];
+#pragma unroll
+        for (int i = 0; i < D4G_HIST / 64; i++) { hr[i] = G.hist[(size_t)m * D4G_HIST + lane + 64 * i]; rr[i] = row[lane + 64 * i]; }
+#pragma unroll
+        for (int i = 0; i < D4G_HIST / 64; i++) { W.hist[lane + 64 * i] = hr[i]; W.delta[lane + 64 * i] = 0; }
+        d4g_wave_sync();
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) d[j] = mw[j] & bw[j];
+        // what the already expanded records of the bin contributed to the static row (they were moved earlier)
+        d4f_wave_for_bits(d, rf, W.queue, [&](const uint4& rv) {
+            const uint32_t a = rv.x;
+            atomicAdd(&W.delta[D4G_BIN_DIST + ref_dsym(a)], 1);
+            atomicAdd(&W.delta[D4G_BIN_COUNT], 1);
+            for_bytes(Ub + rv.y, ref_len(a), [&](int by) { atomicAdd(&W.delta[by], 1); return true; });
+        });
+        d4g_wave_sync();
+#pragma unroll
+        for (int k = 0; k < D4G_HIST / 64; k++) {
+            const int i = lane + 64 * k;
+            if (i <= D4G_BIN_COUNT) {
+                const int moved = (int)rr[k] - W.delta[i];
+                if (moved) {
+                    if (i < 256) atomicAdd(&W.hist[i], (unsigned)moved);
+                    else if (i < D4G_BIN_COUNT) atomicSub(&W.hist[D4G_NLIT + i - D4G_BIN_DIST], (unsigned)moved);
+                    else atomicSub(&W.hist[257 + rem], (unsigned)moved);
+                }
+            }
+        }
+        d4g_wave_sync();
+        uint64_t* O = d4f_mask(c, b, mNew);
+        unsigned long long h1 = 0, h2 = 0;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) {
+            const int w = lane + 64 * j;
+            if (w < nWords) {
+                const uint64_t o = mw[j], n = o | bw[j];
+                O[w] = n;
+                cnt += __popcll(n & ~o);
+                if (n != o) { h1 += d4f_mix1(w, n) - d4f_mix1(w, o); h2 += d4f_mix2(w, n) - d4f_mix2(w, o); }
+            }
+        }
+        cnt = wave_sum_i32(cnt);
+        h1 = (unsigned long long)wave_sum_i64((long long)h1) + F.maskH1[m];
+        h2 = (unsigned long long)wave_sum_i64((long long)h2) + F.maskH2[m];
+        d4g_wave_sync();
+        if (lane == 0) F.maskFull[mNew] = full | (1u << rem);
+        const int mOut = d4f_publish_mask(c, b, G, mNew, h1, h2, F.maskPop[m] + cnt, W.hist);
+        if (lane == 0) { e.mOut = (int16_t)mOut; e.delta = remSize; d4f_fence_block(); e.st = 2; }
+        return;
+    }
     d4f_wave_load_code(W, G.code[code]);
     const bool viaExpanded = 2 * F.maskPop[m] <= nRef;   // walk the smaller side (maskPop counts every expanded record: mask 0's included)
     if (lane < 32) {
@@ -924,6 +1202,7 @@ D4F_TASK void d4f_least_task(int idx) {
     h1 = (unsigned long long)wave_sum_i64((long long)h1) + F.maskH1[m];
     h2 = (unsigned long long)wave_sum_i64((long long)h2) + F.maskH2[m];
     d4g_wave_sync();
+    if (lane == 0) F.maskFull[mNew] = F.maskFull[m] | (1u << rem);
     const int mOut = d4f_publish_mask(c, b, G, mNew, h1, h2, F.maskPop[m] + cnt, W.hist);
     if (lane == 0) { e.mOut = (int16_t)mOut; e.delta = remSize; d4f_fence_block(); e.st = 2; }
 }
@@ -1107,39 +1386,51 @@ D4F_TASK void d4f_hdr_task(int idx) {
 // Huffman rebuild of a mask's histogram (one wave): recodeHuffman — DeflateBlockHuffman.java:670-743 — into the task's
 // scratch; ids are given afterwards by d4f_tree_publish.
 // ---------------------------------------------------------------------------------------
-D4F_TASK void d4f_tree_task(int slotIdx, int m) {
+D4F_TASK void d4f_tree_lit(int slotIdx, int m) {      // wave A of the slot: literal/length tree
     D4FLds& F = d4fLds;
     D4F_CTX;
     D4FTreeScr& T = F.scr.tree[slotIdx];
     const int lane = threadIdx.x & 63;
-    for (int i = lane; i < D4G_HIST; i += 64) T.hist[i] = G.hist[(size_t)m * D4G_HIST + i];
-    for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) ((uint32_t*)T.lens)[i] = 0;
+    for (int i = lane; i < D4G_NLIT; i += 64) T.hist[i] = G.hist[(size_t)m * D4G_HIST + i];
+    for (int i = lane; i < D4G_NLIT / 4; i += 64) ((uint32_t*)T.lens)[i] = 0;
     d4g_wave_sync();
-    int ml = 0, md = 0;
+    int ml = 0;
     for (int i = lane; i < 286; i += 64) if (T.hist[i]) ml = i + 1 > ml ? i + 1 : ml;
+    const int lastLit = wave_max_i32(ml);
+    D4FLitTree tm;
+    tm.carve(T.tree, 1);
+    const int err = d4f_wave_tree<(D4G_NLIT + 63) / 64>(tm, lastLit, 15, [&](int i) { return T.hist[i]; }, [&](int v, int len) { T.lens[v] = (uint8_t)len; });
+    if (lane == 0) { T.nLit = lastLit; T.err = err; T.m = m; }
+    d4g_wave_sync();
+}
+D4F_TASK void d4f_tree_dist(int slotIdx, int m) {     // wave B of the slot: distance tree
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    D4FTreeScr& T = F.scr.tree[slotIdx];
+    const int lane = threadIdx.x & 63;
+    if (lane < D4G_NDIST) { T.hist[D4G_NLIT + lane] = G.hist[(size_t)m * D4G_HIST + D4G_NLIT + lane]; T.lens[D4G_NLIT + lane] = 0; }
+    d4g_wave_sync();
+    int md = 0;
     if (lane < 30 && T.hist[D4G_NLIT + lane]) md = lane + 1;
-    const int lastLit = wave_max_i32(ml), lastDist = wave_max_i32(md);
-    int err = 0;
-    {
-        TreeMem<uint64_t, uint16_t, D4G_NLIT> tm;
-        tm.carve(T.tree, 1);
-        err |= d4f_wave_tree<(D4G_NLIT + 63) / 64>(tm, lastLit, 15, [&](int i) { return T.hist[i]; }, [&](int v, int len) { T.lens[v] = (uint8_t)len; });
+    const int lastDist = wave_max_i32(md);
+    const bool used = lane < lastDist && T.hist[D4G_NLIT + lane] != 0;
+    const int nz = __popcll(__ballot(used));
+    int nDist, err = 0;
+    if (lastDist == 0) nDist = 1;                                  // handleZero: new HuffmanTable(1)
+    else if (nz <= 1) { nDist = lastDist; if (lane == 0) T.lens[D4G_NLIT + lastDist - 1] = 1; }   // handleOne: one used distance code, length 1
+    else {
+        D4FDistTree tm;
+        tm.carve(T.treeD, 1);
+        err = d4f_wave_tree<1>(tm, lastDist, 15, [&](int i) { return T.hist[D4G_NLIT + i]; }, [&](int v, int len) { T.lens[D4G_NLIT + v] = (uint8_t)len; });
+        nDist = lastDist;
     }
+    if (lane == 0) { T.nDist = nDist; T.pad = err; }
     d4g_wave_sync();
-    int nDist;
-    {
-        const bool used = lane < lastDist && T.hist[D4G_NLIT + lane] != 0;
-        const int nz = __popcll(__ballot(used));
-        if (lastDist == 0) nDist = 1;                                  // handleZero: new HuffmanTable(1)
-        else if (nz <= 1) { nDist = lastDist; if (lane == 0) T.lens[D4G_NLIT + lastDist - 1] = 1; }   // handleOne: one used distance code, length 1
-        else {
-            TreeMem<uint64_t, uint16_t, D4G_NDIST> tm;
-            tm.carve(T.tree, 1);
-            err |= d4f_wave_tree<1>(tm, lastDist, 15, [&](int i) { return T.hist[D4G_NLIT + i]; }, [&](int v, int len) { T.lens[D4G_NLIT + v] = (uint8_t)len; });
-            nDist = lastDist;
-        }
-    }
-    d4g_wave_sync();
+}
+D4F_TASK void d4f_tree_header(int slotIdx) {          // wave A again, once both trees stand: token bits and the default header
+    D4FLds& F = d4fLds;
+    D4FTreeScr& T = F.scr.tree[slotIdx];
+    const int lane = threadIdx.x & 63;
     // Σ token bits from the histogram — recodeToHuffmanInternal, :759-770
     long long v = 0;
     for (int i = lane; i < D4G_HIST; i += 64) {
@@ -1151,8 +1442,8 @@ D4F_TASK void d4f_tree_task(int slotIdx, int m) {
     }
     v = wave_sum_i64(v);
     int nPairs, nCl, bits;
-    err |= d4f_wave_default_header(T.lens, lastLit, nDist, T.pairs, T.clFreq, T.clLen, T.tree, nPairs, nCl, bits);
-    if (lane == 0) { T.nLit = lastLit; T.nDist = nDist; T.nCl = nCl; T.nPairs = nPairs; T.hdrBits = bits; T.err = err; T.m = m; T.litlen = v; }
+    const int err = d4f_wave_default_header(T.lens, T.nLit, T.nDist, T.pairs, T.clFreq, T.clLen, T.tree, nPairs, nCl, bits);
+    if (lane == 0) { T.nCl = nCl; T.nPairs = nPairs; T.hdrBits = bits; T.err |= err | T.pad; T.litlen = v; }
     d4g_wave_sync();
 }
 // ids of a finished rebuild (one wave, tasks one after the other): an earlier code with the same lengths is reused
@@ -1230,7 +1521,7 @@ D4F_TASK void d4f_tree_publish(int slotIdx) {
 D4F_TASK void d4f_hs_task(int slotIdx, int code) {
     D4FLds& F = d4fLds;
     D4F_CTX;
-    D4FHsScr& X = F.scr.hs[slotIdx];
+    D4FHsScr& X = ((D4FHsScr*)&F.least)[slotIdx];
     const int lane = threadIdx.x & 63;
     D4GHdrLds& H = X.H;
     uint8_t* comb = X.comb;
@@ -1372,6 +1663,18 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
     const uint64_t* m0 = d4f_mask(c, b, 0);
     for (int w = threadIdx.x; w < (int)b.maskWords; w += blockDim.x) pc += __popcll(m0[w]);
     const long long pop = wg_sum_i64(pc, F.red);
+    {   // length symbols whose records are all expanded in the incoming mask (F.misc[1]: symbols with an unexpanded record)
+        const uint64_t* bmask = c.binMask + b.binMask;
+        const int nWords = (int)b.maskWords;
+        unsigned nf = 0;
+        for (int i = threadIdx.x; i < D4G_NBINS * nWords; i += blockDim.x) {
+            const int bin = i / nWords, w = i - bin * nWords;
+            if (bmask[(long long)bin * nWords + w] & ~m0[w]) nf |= 1u << bin;
+        }
+        if (nf) atomicOr((unsigned*)&F.misc[1], nf);
+        __syncthreads();
+        if (threadIdx.x == 0) F.maskFull[0] = ~(unsigned)F.misc[1] & ((1u << D4G_NBINS) - 1);
+    }
     if (threadIdx.x == 0) {
         c0.nLit = cur->nLit; c0.nDist = cur->nDist; c0.type = curType; c0.err = 0;
         c1.nLit = 0; c1.nDist = 0; c1.type = D4G_FIXED; c1.err = 0;
@@ -1421,16 +1724,16 @@ D4F_TASK bool d4f_select(long long best, D4GRoundResult* out) {
         int mid = ws.m;
         __syncthreads();
         if (ws.lazy) {   // the winner's tokens were never written down: expand E0(code) \ mask now
+            // (the memo table may have been overlaid by the header searches: entry 0 is written afresh; E0 of the code exists,
+            // the state's size came from it)
             if (threadIdx.x == 0) {
-                F.qn[D4F_Q_APPLY] = 0; F.qn[D4F_Q_SWEEP] = 0;
-                F.misc[0] = d4f_req_pass(ws.m, ws.c, 0, 0);
+                F.pass[0].key = 1u + ((uint32_t)ws.m | ((uint32_t)ws.c << 8));
+                F.pass[0].st = 0;
             }
             __syncthreads();
-            if (F.qn[D4F_Q_SWEEP] > 0) d4f_sweep();
+            if (wave == 0) d4f_apply_task(0);
             __syncthreads();
-            if (F.pass[F.misc[0]].st != 2 && wave == 0) d4f_apply_task(F.misc[0]);
-            __syncthreads();
-            mid = F.pass[F.misc[0]].mOut;
+            mid = F.pass[0].mOut;
             if (F.fallback) return false;
         }
         __syncthreads();
@@ -1493,22 +1796,41 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int rounds = 0, info = 0;
+    // optional accounting (D4G_FUSED_STATS): [0,8) tasks per kind, [8,16) steps per kind, [16,24) cycles per kind, 24 advance,
+    // 25 set-up, 26 selection, 27 rounds, 28 steps, 29 cycles in total, 30 / 31 / 32 masks / codes / headers made
+    const bool prof = P.stats != nullptr && threadIdx.x == 0;
+    auto acc = [&](int k, long long v) { if (prof) atomicAdd((unsigned long long*)&P.stats[k], (unsigned long long)v); };
+    const long long tKernel = prof ? clock64() : 0;
     for (;;) {
+        long long tp = prof ? clock64() : 0;
         if (!d4f_round_setup(P.ops[0], P.ops[1], P.nOps[0], P.nOps[1])) { info |= D4F_INFO_FALLBACK; break; }
+        if (prof) { acc(25, clock64() - tp); acc(27, 1); }
         const D4GOp* ops = F.ops;
         const int nOps = F.nOps;
+        // this thread's ops (op i belongs to thread i mod blockDim): the first two stay in registers for the whole round
+        D4GOp myOp0, myOp1;
+        memset(&myOp0, 0, sizeof(myOp0));
+        memset(&myOp1, 0, sizeof(myOp1));
+        if ((int)threadIdx.x < nOps) myOp0 = ops[threadIdx.x];
+        if ((int)(threadIdx.x + blockDim.x) < nOps) myOp1 = ops[threadIdx.x + blockDim.x];
         // ---- the program ----
         long long bestKey = D4G_KEY_NONE;
         int guard = 0;
         for (int iter = 0;; iter++) {
             bool prog2 = false;
-            for (int i = threadIdx.x; i < nOps; i += blockDim.x) prog2 |= d4f_advance_op(&ops[i], i, &bestKey);
+            tp = prof ? clock64() : 0;
+            for (int i = threadIdx.x, n = 0; i < nOps; i += blockDim.x, n++)
+                if (F.opStage[i] != 255 && F.slotReady[n == 0 ? myOp0.src : n == 1 ? myOp1.src : ops[i].src])
+                    prog2 |= d4f_advance_op(n == 0 ? myOp0 : n == 1 ? myOp1 : ops[i], i, &bestKey);
             if (prog2) F.progress[iter & 1] = 1;
             __syncthreads();
+            if (prof) { acc(24, clock64() - tp); acc(28, 1); }
             const int nDone = F.nDone, fb = F.fallback, progressed = F.progress[iter & 1];
             int which = -1;
             for (int q = 0; q < D4F_NQ; q++)
-                if (F.qn[q] > 0) { which = q; break; }
+                if (q != D4F_Q_HS && F.qn[q] > 0) { which = q; break; }
+            // the header searches wait until nothing else can move (their results only rank candidates): all of them at once
+            if (which < 0 && !progressed && F.qn[D4F_Q_HS] > 0) which = D4F_Q_HS;
             if (threadIdx.x == 0) { F.step++; F.progress[(iter + 1) & 1] = 0; }   // (the other flag: read before the previous step's barrier, written after this one)
             __syncthreads();
             if (fb) break;
@@ -1519,7 +1841,7 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
             }
             guard = 0;
             const int nq = F.qn[which] < d4f_qcap(which) ? F.qn[which] : d4f_qcap(which);
-            if (P.stats && threadIdx.x == 0) { atomicAdd((unsigned long long*)&P.stats[which], (unsigned long long)nq); atomicAdd((unsigned long long*)&P.stats[8 + which], 1ULL); }
+            if (prof) { acc(which, nq); acc(8 + which, 1); tp = clock64(); }
             switch (which) {
             case D4F_Q_SWEEP: d4f_sweep(); break;
             case D4F_Q_APPLY:
@@ -1530,13 +1852,24 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
                 for (int t = wave; t < nq; t += nw) d4f_least_task(F.qAll[d4f_qoff(D4F_Q_LEAST) + t]);
                 break;
             case D4F_Q_TREE: {
-                const int nts = nw < D4F_TREE_SLOTS ? nw : D4F_TREE_SLOTS;
+                const int nts = (nw >> 1) < D4F_TREE_SLOTS ? (nw >> 1) : D4F_TREE_SLOTS;   // (at least two waves per workgroup)
                 for (int t0 = 0; t0 < nq; t0 += nts) {
-                    if (wave < nts && t0 + wave < nq) d4f_tree_task(wave, F.qAll[d4f_qoff(D4F_Q_TREE) + t0 + wave]);
+                    const int ts = wave >> 1;
+                    long long tq = prof ? clock64() : 0;
+                    if (ts < nts && t0 + ts < nq) {
+                        const int m = F.qAll[d4f_qoff(D4F_Q_TREE) + t0 + ts];
+                        if (wave & 1) d4f_tree_dist(ts, m); else d4f_tree_lit(ts, m);
+                    }
+                    if (prof) { acc(33, clock64() - tq); tq = clock64(); }
                     __syncthreads();
+                    if (prof) { acc(34, clock64() - tq); tq = clock64(); }
+                    if (ts < nts && t0 + ts < nq && !(wave & 1)) d4f_tree_header(ts);
+                    __syncthreads();
+                    if (prof) { acc(35, clock64() - tq); tq = clock64(); }
                     if (wave == 0)
                         for (int t = 0; t < nts && t0 + t < nq; t++) d4f_tree_publish(t);
                     __syncthreads();
+                    if (prof) { acc(36, clock64() - tq); acc(37, 1); }
                 }
                 break;
             }
@@ -1544,7 +1877,7 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
                 for (int t = wave; t < nq; t += nw) d4f_hdr_task(F.qAll[d4f_qoff(D4F_Q_HDR) + t]);
                 break;
             case D4F_Q_HS: {
-                const int nhs = nw < 2 ? nw : 2;
+                const int nhs = nw < D4F_HS_SLOTS ? nw : D4F_HS_SLOTS;
                 for (int t0 = 0; t0 < nq; t0 += nhs) {
                     if (wave < nhs && t0 + wave < nq) d4f_hs_task(wave, F.qAll[d4f_qoff(D4F_Q_HS) + t0 + wave]);
                     __syncthreads();
@@ -1566,9 +1899,11 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
             default: break;
             }
             __syncthreads();
+            if (prof) acc(16 + which, clock64() - tp);
             if (threadIdx.x == 0) F.qn[which] = 0;
             __syncthreads();
         }
+        if (prof) { acc(30, F.nMask); acc(31, F.nCode); acc(32, F.nHdr); }
         if (F.fallback) { info |= D4F_INFO_FALLBACK; break; }
         // ---- selection ----
         long long best = wave_min_i64(bestKey);
@@ -1577,11 +1912,14 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
         __syncthreads();
         for (int i = 0; i < nw; i++) best = F.red[i] < best ? F.red[i] : best;
         __syncthreads();
+        tp = prof ? clock64() : 0;
         if (!d4f_select(best, &P.results[(size_t)blockIdx.x * D4F_MAXROUNDS + rounds])) { info |= D4F_INFO_FALLBACK; break; }
+        if (prof) acc(26, clock64() - tp);
         rounds++;
         if (!F.improved) break;
         if (rounds >= P.maxRounds || rounds >= D4F_MAXROUNDS) { info |= D4F_INFO_MORE; break; }
     }
     __syncthreads();
+    if (prof) acc(29, clock64() - tKernel);
     if (threadIdx.x == 0) P.roundInfo[blockIdx.x] = rounds | info;
 }

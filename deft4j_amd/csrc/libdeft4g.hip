@@ -964,6 +964,17 @@ long long d4g_test_pack_kinds(void) {
 }
 #endif
 
+// dev tool: the fused executor's accounting (collected while D4G_FUSED_STATS is set; see k_search_fused); read and cleared
+int d4g_debug_fused_stats(long long* out64) {
+    D4G_API_LOCK();
+    d4g::engine().init();
+    rt_sync_all();
+    rt_d2h(out64, d4g::engine().dOpStats, 64 * 8);
+    rt_memset(d4g::engine().dOpStats, 0, 64 * 8);
+    rt_sync();
+    return 0;
+}
+
 #ifdef D4G_PROFILE_OPS
 // profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
 int d4g_debug_set_experiment(long long mode) {

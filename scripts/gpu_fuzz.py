@@ -18,7 +18,7 @@ SIM = "--sim" in sys.argv
 LIB = None
 if SIM:
     os.environ.setdefault("D4G_SIM_BLOCK", "64")
-    LIB = D.load_library(os.path.join(ROOT, "tests", "hostsim", "libdeft4g_hostsim.so"))
+    LIB = D.load_library(os.path.join(ROOT, "tests", "hostsim", os.environ.get("D4G_SIM_LIB", "libdeft4g_hostsim.so")))
 D.init(0, lib=LIB)
 
 

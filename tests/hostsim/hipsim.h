@@ -109,6 +109,7 @@ inline unsigned atomicCAS(unsigned* p, unsigned expect, unsigned v) {
     return o;
 }
 inline void __threadfence() {}
+inline long long clock64() { return 0; }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }

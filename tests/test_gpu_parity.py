@@ -65,9 +65,10 @@ def _oracle_many(ins, merge):
 
 
 @pytest.mark.parametrize("merge", [False, True])
-def test_levels_executor_large_batch_vs_oracle(D, merge):
-    """More than 128 dynamic blocks in one batch, so the default executor choice is `levels` with two stream lanes
-    (the launch sequencing bench.py times): 28 x 1 MiB reptext members, every output byte-compared with the oracle."""
+def test_levels_executor_large_batch_vs_oracle(D, merge, monkeypatch):
+    """More than 128 dynamic blocks in one batch, so without the fused executor the choice is `levels` with two stream lanes
+    (round 2's launch sequencing): 28 x 1 MiB reptext members, every output byte-compared with the oracle."""
+    monkeypatch.setenv("D4G_EXEC", "auto")   # the level / persistent executors, chosen by block count
     raws = [synth.reptext(1 << 20, 0x5EED + i) for i in range(28)]
     ins = [synth.deflate9(r) for r in raws]
     b = D.Batch(ins).run(merge)
