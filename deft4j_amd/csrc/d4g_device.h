@@ -643,7 +643,7 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
             else if (lane == k || selfGreater) hv = x;
         }
     };
-    auto poll = [&]() -> unsigned D4G_LAMBDA_INLINE {
+    auto poll = [&]() D4G_LAMBDA_INLINE -> unsigned {
         const unsigned out = (unsigned)d4g_readlane((int)hv, 0);
         const int s = --hs;
         if (s == 0) return out;

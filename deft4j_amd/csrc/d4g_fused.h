@@ -183,18 +183,10 @@ struct D4FLds {
     uint32_t maskFull[D4F_MAXM];      // length symbols known to have every record expanded (bit per symbol): they take no part in least-expensive pruning
     alignas(4) uint16_t maskHash[512];           // id + 1 by maskH1
     uint16_t maskStep[D4F_MAXM];      // step in which the mask was published (content is compared only with masks of earlier steps: their words are visible)
-    unsigned long long codeH[D4F_MAXC];
-    uint8_t codeHash[256];            // id + 1 by codeH
     int16_t defHdr[D4F_MAXC];         // header id of the code's default header, -1: not built
-    alignas(4) uint8_t eState[D4F_MAXC];         // E-sets of the code: 0 none, 1 queued, 2 there
-    uint8_t eEq[D4F_MAXC];            // both comparison modes expand the same records
-    alignas(4) uint8_t bbState[D4F_MAXC];        // per-length-symbol sums of the code
-    alignas(4) uint8_t hsState[D4F_MAXC];
-    int32_t hsBits[D4F_MAXC];
-    uint8_t hsLane[D4F_MAXC];
     uint16_t qAll[D4F_QTOTAL];
     int32_t qn[D4F_NQ];
-    int32_t nMask, nCode, nHdr, nDone, fallback, progress[2], fixdotSt, fixdotM, step;
+    int32_t nMask, nHdr, nDone, fallback, progress[2], fixdotSt, fixdotM, step, pad0;
     long long fixdotLit;
     long long red[32];
     int32_t misc[32];
@@ -204,7 +196,19 @@ struct D4FLds {
     D4FHdrE hdrReq[D4F_HDRN];
     D4FPassE pass[D4F_PASSN];
     D4FScratch scr;
-    // not cleared between rounds: what the kernel was called with, the block, the round in progress
+    // ---- not cleared between rounds ----
+    // The code table: what is known about a code is a function of its lengths (and the block's records), not of the
+    // round — E-sets, per-length-symbol sums, header-search results stay valid while the launch runs its rounds.
+    unsigned long long codeH[D4F_MAXC];
+    alignas(4) uint8_t codeHash[256];            // id + 1 by codeH
+    alignas(4) uint8_t eState[D4F_MAXC];         // E-sets of the code: 0 none, 1 queued, 2 there
+    alignas(4) uint8_t eEq[D4F_MAXC];            // both comparison modes expand the same records
+    alignas(4) uint8_t bbState[D4F_MAXC];        // per-length-symbol sums of the code
+    alignas(4) uint8_t hsState[D4F_MAXC];
+    int32_t hsBits[D4F_MAXC];
+    alignas(4) uint8_t hsLane[D4F_MAXC];
+    int32_t nCode, pad2;
+    // what the kernel was called with, the block, the round in progress
     D4GCtx c;
     D4GBlock b;
     D4FGlob G;
@@ -214,7 +218,7 @@ struct D4FLds {
 };
 
 static_assert(sizeof(D4FLds) <= 80 * 1024, "two workgroups per CU: 80 KiB of LDS each");
-static_assert(offsetof(D4FLds, c) - offsetof(D4FLds, least) >= D4F_HS_SLOTS * sizeof(D4FHsScr), "header-search scratch overlay");
+static_assert(offsetof(D4FLds, codeH) - offsetof(D4FLds, least) >= D4F_HS_SLOTS * sizeof(D4FHsScr), "header-search scratch overlay");
 // The workgroup's LDS, at namespace scope: the task functions below are real calls (one register budget each instead of
 // one for the whole kernel) and still address it with LDS instructions.
 __shared__ D4FLds d4fLds;
@@ -1484,6 +1488,7 @@ D4F_TASK void d4f_tree_publish(int slotIdx) {
                 F.nCode = code + 1;
                 F.codeH[code] = h;
                 F.defHdr[code] = -1;
+                F.eState[code] = 0; F.eEq[code] = 0; F.bbState[code] = 0; F.hsState[code] = 0;
                 F.codeHash[k] = (uint8_t)(code + 1);   // k: the first empty slot of the probe above
             }
         }
@@ -1643,8 +1648,14 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
     __syncthreads();
     if (threadIdx.x == 0) { F.ops = prog ? ops1 : ops0; F.nOps = nOps; F.curType = curType; F.curSize = cur->sizeBits; }
     if (nOps > D4F_MAXOPS || c.slotsPerBlock > D4F_MAXSLOTS) { __syncthreads(); return false; }
-    D4FCode& c0 = G.code[0];
-    for (int i = threadIdx.x; i < (D4G_NLIT + D4G_NDIST) / 4; i += blockDim.x) ((uint32_t*)c0.lens)[i] = ((const uint32_t*)cur->litLen)[i];
+    if (F.nCode > D4F_MAXC - 32) {   // the code table is nearly full: start it afresh (all threads see the same count)
+        __syncthreads();
+        for (int i = threadIdx.x; i < D4F_MAXC; i += blockDim.x) { F.eState[i] = 0; F.eEq[i] = 0; F.bbState[i] = 0; F.hsState[i] = 0; }
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) F.codeHash[i] = 0;
+        if (threadIdx.x == 0) F.nCode = 2;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < D4F_MAXC; i += blockDim.x) F.defHdr[i] = -1;
     D4FCode& c1 = G.code[D4F_CODE_FIXED];
     for (int i = threadIdx.x; i < D4G_NLIT + D4G_NDIST; i += blockDim.x)
         c1.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 286 ? 8 : i < D4G_NLIT ? 0 : i < D4G_NLIT + 30 ? 5 : 0);   // HuffmanTable.LIT / DIST :166-209
@@ -1675,29 +1686,58 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
         __syncthreads();
         if (threadIdx.x == 0) F.maskFull[0] = ~(unsigned)F.misc[1] & ((1u << D4G_NBINS) - 1);
     }
+    // the incoming state's code: found in / added to the code table
+    if (wave == 0) {
+        const uint32_t* cw = (const uint32_t*)cur->litLen;
+        const uint32_t w0 = cw[lane], w1 = lane < 16 ? cw[64 + lane] : 0u;
+        const int nLit0 = cur->nLit, nDist0 = cur->nDist;
+        unsigned long long h = d4f_mix1(lane, w0) + (lane < 16 ? d4f_mix1(64 + lane, w1) : 0ull);
+        h = (unsigned long long)wave_sum_i64((long long)h) + (unsigned long long)nLit0 * 0x100000001b3ULL + ((unsigned long long)nDist0 << 48) +
+            (curType == D4G_DYNAMIC ? 0ull : 0x9e3779b97f4a7c15ULL);
+        if (h == 0) h = 1;
+        int found = -1;
+        uint32_t k = (uint32_t)(h >> 40) & 255u;
+        for (int probe = 0; probe < 256; probe++, k = (k + 1) & 255u) {
+            const int e = F.codeHash[k];
+            if (e == 0) break;
+            const int id = e - 1;
+            if (F.codeH[id] == h) {
+                const D4FCode& cd = G.code[id];
+                int bad = ((const uint32_t*)cd.lens)[lane] != w0;
+                if (lane < 16) bad |= ((const uint32_t*)cd.lens)[64 + lane] != w1;
+                if (lane == 0) bad |= cd.nLit != nLit0 || cd.nDist != nDist0 || cd.type != curType;
+                if (!__ballot(bad)) { found = id; break; }
+            }
+        }
+        const int nCodeNow = __shfl(F.nCode, 0);
+        int code = found;
+        if (code < 0) {
+            code = nCodeNow;   // (the table was emptied above when it was nearly full: there is room)
+            D4FCode& cd = G.code[code];
+            ((uint32_t*)cd.lens)[lane] = w0;
+            if (lane < 16) ((uint32_t*)cd.lens)[64 + lane] = w1;
+            if (lane == 0) {
+                cd.nLit = nLit0; cd.nDist = nDist0; cd.type = curType; cd.err = 0;
+                F.nCode = code + 1;
+                F.codeH[code] = h;
+                F.codeHash[k] = (uint8_t)(code + 1);
+                F.eState[code] = 0; F.eEq[code] = 0; F.bbState[code] = 0; F.hsState[code] = 0;
+            }
+        }
+        if (lane == 0) F.misc[2] = code;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        c0.nLit = cur->nLit; c0.nDist = cur->nDist; c0.type = curType; c0.err = 0;
         c1.nLit = 0; c1.nDist = 0; c1.type = D4G_FIXED; c1.err = 0;
         p0.nPairs = np;
         h0.nCl = cur->nCl; h0.bits = (int32_t)cur->hdrBits; h0.base = 0;
         F.hdrBits[0] = curType == D4G_DYNAMIC ? (int32_t)cur->hdrBits : 0;
-        F.nMask = 1; F.nCode = 2; F.nHdr = 1; F.step = 1;
+        F.nMask = 1; F.nHdr = 1; F.step = 1;
         F.maskPop[0] = (int)pop;
-        F.defHdr[0] = -1; F.defHdr[1] = -1;
         D4FSlot s;
-        s.m = 0; s.c = 0; s.h = 0; s.valid = 1; s.type = (uint8_t)curType; s.lazy = 0; s.litlen = cur->litlenBits;
+        s.m = 0; s.c = (int16_t)F.misc[2]; s.h = 0; s.valid = 1; s.type = (uint8_t)curType; s.lazy = 0; s.litlen = cur->litlenBits;
         F.slot[0] = s;
         F.slotReady[0] = 1;
-    }
-    __syncthreads();
-    // code 0 joins the content table (a rebuild that arrives at the same lengths shares its sweeps and header searches)
-    if (wave == 0 && curType == D4G_DYNAMIC) {
-        unsigned long long h = 0;
-        const uint32_t* lw = (const uint32_t*)G.code[0].lens;
-        for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) h += d4f_mix1(i, lw[i]);
-        h = (unsigned long long)wave_sum_i64((long long)h) + (unsigned long long)G.code[0].nLit * 0x100000001b3ULL + ((unsigned long long)G.code[0].nDist << 48);
-        if (h == 0) h = 1;
-        if (lane == 0) { F.codeH[0] = h; F.codeHash[(uint32_t)(h >> 40) & 255u] = 1; }
     }
     __syncthreads();
     return true;
@@ -1787,8 +1827,11 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
 #endif
     D4FLds& F = d4fLds;
     if ((int)blockIdx.x >= cArg.nActive) return;
+    for (int i = threadIdx.x; i < D4F_MAXC; i += blockDim.x) { F.eState[i] = 0; F.eEq[i] = 0; F.bbState[i] = 0; F.hsState[i] = 0; }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) F.codeHash[i] = 0;
     if (threadIdx.x == 0) {
         const int blk = cArg.active[blockIdx.x];
+        F.nCode = 2;
         F.c = cArg;
         F.b = cArg.blocks[blk];
         F.G = d4f_glob(cArg, blk);

@@ -65,19 +65,27 @@ struct RtGlobals {
         // A thread that is about to run kernels lasting minutes (the Zopfli squeeze) asks for low-priority streams: HIP multiplexes
         // its streams onto a few hardware queues per priority level, and a queue stays busy until its kernel ends — normal-priority
         // streams of other threads that landed on the same queue would wait behind it (measured: a candidate search held up for 78 s).
-        int least = 0, greatest = 0;
-        if (rt_low_priority_thread()) RT_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < RT_MAX_LANES; k++) {
-            if (rt_low_priority_thread()) {
-                RT_CHECK(hipStreamCreateWithPriority(&a[k], hipStreamNonBlocking, least));
-                RT_CHECK(hipStreamCreateWithPriority(&b[k], hipStreamNonBlocking, least));
-            } else {
-                RT_CHECK(hipStreamCreateWithFlags(&a[k], hipStreamNonBlocking));
-                RT_CHECK(hipStreamCreateWithFlags(&b[k], hipStreamNonBlocking));
-            }
-        }
+        // Only lane 0 now, the other lanes when a level-executor round first uses them: HIP hands its hardware queues to streams
+        // in creation order, and a thread that created sixteen streams up front pushed the next thread's main stream back onto
+        // the first thread's queue — where that thread's candidate search (one launch of milliseconds) held up the other batch's
+        // parse (measured: two batches in flight 9.7 ms per step when they collided, 7.0 when they did not).
         made = true;
+        make_lane(0);
     }
+    void make_lane(int k) {
+        if (a[k]) return;
+        int least = 0, greatest = 0;
+        if (rt_low_priority_thread()) {
+            RT_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            RT_CHECK(hipStreamCreateWithPriority(&a[k], hipStreamNonBlocking, least));
+            RT_CHECK(hipStreamCreateWithPriority(&b[k], hipStreamNonBlocking, least));
+        } else {
+            RT_CHECK(hipStreamCreateWithFlags(&a[k], hipStreamNonBlocking));
+            RT_CHECK(hipStreamCreateWithFlags(&b[k], hipStreamNonBlocking));
+        }
+    }
+    hipStream_t sa() { make_lane(cur); return a[cur]; }
+    hipStream_t sb() { make_lane(cur); return b[cur]; }
     void destroy_streams() {
         if (!made) return;
         for (int k = 0; k < RT_MAX_LANES; k++) {
@@ -86,7 +94,7 @@ struct RtGlobals {
         }
         made = false;
     }
-    hipStream_t& stream_ref() { return a[cur]; }
+    hipStream_t& stream_ref() { make_lane(cur); return a[cur]; }
 };
 inline RtGlobals& rt() {
     thread_local RtGlobals g;
@@ -155,14 +163,14 @@ inline void rt_pool_release() {   // d4g_shutdown
     P.freeBlocks.clear();
     P.heldBytes = 0;
 }
-inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().a[rt().cur])); }
+inline void rt_h2d(void* d, const void* h, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, rt().sa())); }
 inline void rt_d2h(void* h, const void* d, size_t n) {
-    if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().a[rt().cur]));
-    RT_CHECK(hipStreamSynchronize(rt().a[rt().cur]));
+    if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, rt().sa()));
+    RT_CHECK(hipStreamSynchronize(rt().sa()));
 }
-inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().a[rt().cur])); }
-inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().a[rt().cur])); }
-inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().a[rt().cur])); }
+inline void rt_d2d(void* d, const void* s, size_t n) { if (n) RT_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, rt().sa())); }
+inline void rt_memset(void* d, int v, size_t n) { if (n) RT_CHECK(hipMemsetAsync(d, v, n, rt().sa())); }
+inline void rt_sync() { RT_CHECK(hipStreamSynchronize(rt().sa())); }
 inline void rt_sync_all() {
     for (int k = 0; k < RT_MAX_LANES; k++) {
         if (rt().a[k]) RT_CHECK(hipStreamSynchronize(rt().a[k]));
@@ -171,7 +179,7 @@ inline void rt_sync_all() {
 }
 #define RT_LAUNCH(kern, grid, block, ...)                                                           \
     do {                                                                                            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().a[rt().cur], __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().sa(), __VA_ARGS__); \
         RT_CHECK(hipGetLastError());                                                                \
     } while (0)
 
@@ -179,14 +187,14 @@ struct RtEvent {
     hipEvent_t e = nullptr;
     RtEvent() { RT_CHECK(hipEventCreate(&e)); }
     ~RtEvent() { if (e) (void)hipEventDestroy(e); }
-    void record() { RT_CHECK(hipEventRecord(e, rt().a[rt().cur])); }
-    void record2() { RT_CHECK(hipEventRecord(e, rt().b[rt().cur])); }
+    void record() { RT_CHECK(hipEventRecord(e, rt().sa())); }
+    void record2() { RT_CHECK(hipEventRecord(e, rt().sb())); }
 };
-inline void rt_stream2_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().b[rt().cur], ev.e, 0)); }
-inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().a[rt().cur], ev.e, 0)); }
+inline void rt_stream2_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().sb(), ev.e, 0)); }
+inline void rt_stream_wait(RtEvent& ev) { RT_CHECK(hipStreamWaitEvent(rt().sa(), ev.e, 0)); }
 #define RT_LAUNCH2(kern, grid, block, ...)                                                          \
     do {                                                                                            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().b[rt().cur], __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, rt().sb(), __VA_ARGS__); \
         RT_CHECK(hipGetLastError());                                                                \
     } while (0)
 inline int device_cus() {
