@@ -367,7 +367,7 @@ def detect(data):
 
 def optimise_files(files, merge_blocks=True, formats=None, lib=None, mode=0):
     """files: list of bytes.  formats: optional list of container instances / None (auto-detect) / "raw".
-    mode: RecompressMode ordinal of `deft4j optimise --mode` (0 NONE, 1 CHEAP; M/CMDUtil.java:44-50,76-105): above NONE every
+    mode: RecompressMode ordinal of `deft4j optimise --mode` (0 NONE, 1 CHEAP, 2 ZOPFLI, 3 ZOPFLI_EXTENSIVE, 4 ZOPFLI_VERY_EXTENSIVE; M/CMDUtil.java:44-50,76-105): above NONE every
     stream is also recompressed and the recompression grafted in where it is smaller.
     Returns [(output bytes or None when unreadable, transcript lines)] — the lines M/CMDUtil.java:64-74 and
     K/DeflateFilesContainer.java:31-40 print.  Every deflate stream of every file goes to the GPU in one batch."""

@@ -1102,6 +1102,7 @@ struct Batch {
         rt_free(dRes); rt_free(dInfo);
         return chains;
     }
+    bool forceLevels = false;   // the round in hand fell back from the persistent executor
     std::vector<D4GRoundResult> run_round_legacy(const std::vector<int>& act) {
         Engine& E = engine();
         std::vector<D4GRoundResult> res(act.size());
@@ -1116,7 +1117,7 @@ struct Batch {
             int nA = (int)sub.size();
             rt().cur = 0;
             int xoff[9] = {0};
-            const bool persist = exec_persistent(nA) != 0;
+            const bool persist = !forceLevels && exec_persistent(nA) != 0;
             if (persist) {
                 // group the active blocks by (position mod 8): one task queue per XCD
                 std::vector<int32_t> g;
@@ -1138,8 +1139,10 @@ struct Batch {
                 D4GCtx c = make_ctx(P, nA);
                 epoch++;
                 rt_memset(dHeads, 0, 64);
-                D4GQueue qs = {P.dStateFlat, P.nStateFlat, dHeads, dReady, epoch, {0}};
-                D4GQueue qh = {P.dHdrFlat, P.nHdrFlat, dHeads + 8, dReady, epoch, {0}};
+                const char* sl = getenv("D4G_SPIN_LIMIT");
+                const long long spinLimit = sl ? atoll(sl) : (1LL << 21);
+                D4GQueue qs = {P.dStateFlat, P.nStateFlat, dHeads, dReady, epoch, {0}, spinLimit};
+                D4GQueue qh = {P.dHdrFlat, P.nHdrFlat, dHeads + 8, dReady, epoch, {0}, spinLimit};
                 for (int x = 0; x < 9; x++) { qs.xoff[x] = xoff[x]; qh.xoff[x] = xoff[x]; }
                 RtEvent ready;
                 ready.record();
@@ -1236,6 +1239,18 @@ struct Batch {
             rt_d2h(r.data(), dResults, sub.size() * sizeof(D4GRoundResult));
             const float roundMs = rt_elapsed_ms(e0, e1);
             msSearch += roundMs;
+            if (persist && !r.empty() && r[0].improved < 0) {
+                // a wait inside the persistent kernels gave up (see wg_wait_slot): nothing was selected, the blocks are
+                // untouched — the same round again with the level executor, which has no cross-kernel waits
+                int32_t zero[2] = {0, 0};
+                rt_h2d(errors() + 1, zero, 4);
+                rt_sync();
+                stats.persist_fallbacks++;
+                forceLevels = true;
+                pass--;
+                continue;
+            }
+            forceLevels = false;
             if (getenv("D4G_DEBUG_ROUNDS"))
                 fprintf(stderr, "search round %lld (%s program, %s): %d active blocks, %.3f ms\n", (long long)stats.rounds, pass == 0 ? "dynamic" : "fixed",
                         persist ? "persistent" : "levels", nA, roundMs);

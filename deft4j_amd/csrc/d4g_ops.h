@@ -1233,6 +1233,7 @@ struct D4GQueue {
     int32_t* ready;          // [numBlocks * slotsPerBlock]: epoch in which the slot was last produced
     int32_t epoch;
     int32_t xoff[9];         // the active list is grouped by XCD: group x = active[xoff[x], xoff[x+1])
+    long long spinLimit;     // polls before a wait gives up (D4G_SPIN_LIMIT; < 0: every wait gives up at once — tests)
 };
 
 // Pull the next task: first from the queue of this workgroup's XCD (workgroup ids equal mod 8 share an XCD
@@ -1270,20 +1271,24 @@ D4G_DEV void wg_copy_mask(uint64_t* dst, const uint64_t* src, long long words) {
     __syncthreads();
 }
 
-// All threads call.  Returns false if the slot never became ready (bounded spin; counted as a device error).
+// All threads call.  Returns false if the slot never became ready: the producer runs in another workgroup (for header
+// searches: another kernel), and HIP promises no co-residency — under a profiler that serialises kernels, or with the
+// device full of someone else's long kernel, a wait can outlast any bound.  That is not an error: it is counted in
+// c.errors[1], k_select then leaves the block untouched and the host runs the round with the level executor.
 __device__ bool wg_wait_slot(const D4GCtx& c, const D4GQueue& q, int blk, int slot, int* lds) {
     if (slot == 0) return true;  // the block's current state was written by an earlier kernel
     __syncthreads();
     if (threadIdx.x == 0) {
         const int32_t* f = q.ready + (long long)blk * c.slotsPerBlock + slot;
         int ok = 0;
-        // bounded: ~1 s in total, and every waiter gives up as soon as any other has failed
-        for (long long spin = 0; spin < (1LL << 21); spin++) {
+        // bounded: ~1 s in total by default, and every waiter gives up as soon as any other has
+        for (long long spin = 0; spin < q.spinLimit; spin++) {
             if (d4g_flag_load(f) == q.epoch) { ok = 1; break; }
-            if ((spin & 63) == 63 && d4g_flag_load(c.errors) != 0) break;
+            if ((spin & 63) == 63 && d4g_flag_load(c.errors + 1) != 0) break;
             d4g_sleep();
         }
-        if (!ok) atomicAdd(c.errors, 1);
+        if (!ok && q.spinLimit >= 0 && d4g_flag_load(f) == q.epoch) ok = 1;
+        if (!ok) atomicAdd(c.errors + 1, 1);
         *lds = ok;
     }
     __syncthreads();
@@ -1846,6 +1851,14 @@ __global__ void __launch_bounds__(256) k_select(D4GCtx c, D4GRoundResult* result
     const D4GBlock b = c.blocks[blk];
     D4GState* S = &L.st;
     D4GState* cur = state_ptr(c, blk, 0);
+    if (d4g_flag_load(c.errors + 1) != 0) {   // a wait of the persistent executor gave up: the keys are incomplete — nothing is selected
+        if (threadIdx.x == 0) {
+            D4GRoundResult r;
+            r.curSize = cur->sizeBits; r.bestSize = cur->sizeBits; r.bestSeq = -1; r.improved = -1; r.newType = cur->type; r.pad = 0;
+            results[blockIdx.x] = r;
+        }
+        return;
+    }
     const long long* keys = c.keys + (long long)blk * c.nOps;
     long long best = D4G_KEY_NONE;
     for (int i = threadIdx.x; i < c.nOps; i += blockDim.x) best = keys[i] < best ? keys[i] : best;

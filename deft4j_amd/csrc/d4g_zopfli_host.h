@@ -70,6 +70,7 @@ struct ZfFront {
         }
         dIn = upload(hIn);
         pool.cap = (uint32_t)std::min<i64>(total / 2 + (1 << 16), 0x7fff0000LL);
+        if (const char* pw = getenv("D4G_ZF_POOL_WORDS")) pool.cap = (uint32_t)std::max(64, atoi(pw));   // tests: start small, exercise the growth
         pool.words = dalloc<uint32_t>(pool.cap);
         pool.used = dalloc<uint32_t>(4, true);
         pool.error = (int32_t*)(pool.used + 1);
@@ -101,10 +102,7 @@ struct ZfFront {
                     mj.push_back({(int32_t)i, (int32_t)std::min<i64>(per, len[i] - p), p, len[i], hIn[i].table + p * 8, hIn[i].best + p});
             if (!mj.empty()) {
                 ZfMatchJob* dM = upload(mj);
-                RT_LAUNCH(k_zf_match_sorted, mj.size(), ZF_MS_THREADS, dIn, dM, pool);
-                int32_t err = 0;
-                rt_d2h(&err, pool.error, 4);
-                if (err) throw std::runtime_error("zopfli match table: change-point pool exhausted");
+                with_pool_retry([&]() { RT_LAUNCH(k_zf_match_sorted, mj.size(), ZF_MS_THREADS, dIn, dM, pool); });
             }
         }
         msTable += now_ms() - t0;
@@ -112,11 +110,33 @@ struct ZfFront {
     void run_match(const std::vector<ZfMatchJob>& mj) {
         if (mj.empty()) return;
         ZfMatchJob* dM = upload(mj);
-        RT_LAUNCH(k_zf_match, mj.size(), ZF_MATCH_THREADS, dIn, dM, pool);
-        int32_t err = 0;
-        rt_d2h(&err, pool.error, 4);
-        if (err) throw std::runtime_error("zopfli match table: change-point pool exhausted");
+        with_pool_retry([&]() { RT_LAUNCH(k_zf_match, mj.size(), ZF_MATCH_THREADS, dIn, dM, pool); });
     }
+    // The change-point pool is sized for ordinary data (half a word per input byte); inputs whose positions have many
+    // record-setting matches need more.  A launch that ran out of room is run again with twice the pool — what earlier
+    // launches stored is kept, the failed launch's entries are all rewritten — instead of failing the whole batch
+    // (the reference never fails on valid input, C/CompressionUtil.java:151-173).
+    uint32_t poolUsedHost = 0;
+    template <typename Launch>
+    void with_pool_retry(Launch launch) {
+        for (int attempt = 0;; attempt++) {
+            launch();
+            uint32_t st[2] = {0, 0};
+            rt_d2h(st, pool.used, 8);   // {used, error}
+            if (!st[1]) { poolUsedHost = st[0]; return; }
+            if (attempt >= 16 || pool.cap >= 0x7fff0000u) throw std::runtime_error("zopfli match table: change-point pool exhausted");
+            const uint32_t newCap = (uint32_t)std::min<i64>((i64)pool.cap * 2, 0x7fff0000LL);
+            uint32_t* nw = dalloc<uint32_t>(newCap);
+            if (poolUsedHost) rt_d2d(nw, pool.words, (size_t)poolUsedHost * 4);
+            pool.words = nw;
+            pool.cap = newCap;
+            const uint32_t z[2] = {poolUsedHost, 0};
+            rt_h2d(pool.used, z, 8);
+            rt_sync();
+            poolGrowths++;
+        }
+    }
+    int poolGrowths = 0;
 
     // ---- tails ----
     struct Tail { i64 start; uint32_t* table; uint32_t* best; };
@@ -181,7 +201,8 @@ struct ZfFront {
         uint32_t* dNp = dalloc<uint32_t>(n + 1, true);
         int32_t* dErr = (int32_t*)dalloc<uint32_t>(1, true);
         for (size_t k = 0; k < n; k++) {
-            const uint32_t cap = maxblocks[k] ? maxblocks[k] : 4096;
+            // unlimited splitting (blocksplittingmax 0): split points are at least ten symbols apart
+            const uint32_t cap = maxblocks[k] ? maxblocks[k] : (uint32_t)(stores[k].size / 10 + 2);
             dPts[k] = dalloc<uint32_t>(cap + 1);
             dBp[k] = dalloc<uint32_t>(cap + 1);
             jobs[k] = {dev(stores[k]), maxblocks[k], cap, dalloc<uint8_t>(stores[k].size + 8, true), dPts[k], dBp[k], dNp + k, dErr};

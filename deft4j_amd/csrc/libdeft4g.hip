@@ -45,7 +45,8 @@ int fail(int code, const std::string& msg) {
 }
 bool ready() { return rt().ready; }
 // HIP's current device is per thread: CompressionUtil's pool threads (and any rank with device != 0) must bind
-// the library's device before allocating or launching.  Called under g_mu at the top of every entry point.
+// the library's device before allocating or launching.  Called at the top of every entry point (d4g_init / d4g_shutdown hold g_mu;
+// the others run concurrently, each on its calling thread).
 void bind_device() {
 #ifndef D4G_HOSTSIM
     if (rt().ready && rt().device >= 0) RT_CHECK(hipSetDevice(rt().device));

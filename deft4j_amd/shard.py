@@ -43,7 +43,8 @@ def optimise_sharded(sizes, load, merge_blocks, make_batch, dist=None, device="c
     the caller's shard.  `make_batch(list_of_bytes)` returns an object with run(merge) / result(i) / output(i) / close()
     (deft4j_amd.Batch); `run(batch)` overrides the default batch.run(merge_blocks) (e.g. a recompress mode).
     Rank 0 gets (total_saved, outputs, per_stream_saved) with outputs[i] = the new bytes or None (unchanged / did not
-    parse: the caller keeps its original); other ranks get None."""
+    parse: the caller keeps its original); other ranks get None.  saved = what DeflateStream.optimise saved on the
+    stream plus, in a recompress run, what the grafted recompressed stream saved on top (M/CMDUtil.java:95-103)."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     n = len(sizes)
@@ -64,6 +65,13 @@ def optimise_sharded(sizes, load, merge_blocks, make_batch, dist=None, device="c
                 o = b.output(k)
                 outs[i] = o
                 meta[i, 1] = r["saved_bits"]
+                if run is not None and hasattr(b, "recompress_result"):
+                    try:
+                        grafted, rsaved = b.recompress_result(k)
+                        if grafted:
+                            meta[i, 1] += rsaved
+                    except Exception:  # noqa: BLE001 — the batch was not run in a recompress mode
+                        pass
                 meta[i, 2] = len(o)
         b.close()
     if dist is None or world == 1:

@@ -11,9 +11,13 @@
  * d4g_last_error()).  Nothing here has a CPU fallback: without a usable HIP device
  * d4g_init() fails and every other call returns D4G_ERR_NODEVICE.
  *
- * SCOPE: mode NONE (parse, candidate search, mergeBlocks, write) and the zlib-family recompress path (JavaCompressor /
- * JZLibCompressor at level 9, CompressionUtil.compress and CMDUtil's recompress loop for mode CHEAP) are built.  The Zopfli
- * compressors (CafeUndZopfli, JZopfli) are NOT: modes ZOPFLI and above return D4G_ERR_ARG — never a substitute result.
+ * SCOPE: mode NONE (parse, candidate search, mergeBlocks, write) and every recompress mode are built: the zlib-family
+ * compressors (JavaCompressor / JZLibCompressor at level 9), the Zopfli compressors (CafeUndZopfli FIRST / LAST / NONE,
+ * JZopfli's five option sets), CompressionUtil.compress and CMDUtil's recompress loop for modes CHEAP, ZOPFLI,
+ * ZOPFLI_EXTENSIVE and ZOPFLI_VERY_EXTENSIVE.  An unknown mode returns D4G_ERR_ARG — never a substitute result.
+ *
+ * LIMITS (reported as errors of the call, never as a wrong result): one input of 2 GiB or more; 2^32 or more back-references
+ * in one batch (split it); a Zopfli master block above 8 MiB (deft4j uses 8 MiB and 1 MB).
  *
  * THREADS: d4g_init / d4g_shutdown are exclusive.  Everything else may be called from several host threads at once
  * (CompressionUtil's pool, C/CompressionUtil.java:111-117): every thread gets its own HIP streams; a d4g_batch is used by
@@ -68,6 +72,8 @@ typedef struct d4g_stats {
     int64_t zopfli_blocks, zopfli_position_iterations;
     /* fused executor (one workgroup per block, all rounds): optimiseBlock rounds it ran, rounds handed to the level executor */
     int64_t rounds_fused, fused_fallbacks;
+    /* rounds of the persistent executor that were run again by the level executor because a cross-kernel wait gave up */
+    int64_t persist_fallbacks;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.
@@ -126,8 +132,7 @@ int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_l
 /* ---- recompress modes (deft4j-cmd/.../cmd/CMDUtil.java:44-50, Optimise.java `--mode`) ----
  * mode = ordinal of RecompressMode: the compressor list CompressionUtil.getCompressors builds for it (:44-78), in list
  * order JVM{DEFAULT, FILTERED, HUFFMAN_ONLY}, [JZopfli], [CafeUndZopfli], JZlib{DEFAULT, FILTERED, HUFFMAN_ONLY}.
- * Only the zlib-family compressors are built: modes that need a Zopfli compressor fail with D4G_ERR_ARG (no silent
- * substitute).  `iter` (Zopfli iterations) is accepted for signature parity and unused by the built modes. */
+ * `iter` = Zopfli iterations (-I of the reference CLI, default 20), used by the modes from ZOPFLI up. */
 /* ---- Zopfli encoder (the recompress modes ZOPFLI / ZOPFLI_EXTENSIVE / ZOPFLI_VERY_EXTENSIVE) ----
  * MultiCafeUndZopfliCompressor.compressWithOptions (C/MultiCafeUndZopfliCompressor.java:48-52: CafeUndZopfli, master block
  * 8 << 20, BlockSplitting FIRST / LAST / NONE, `iter` iterations) and MultiJZopfliCompressor.compressWithOptions

@@ -225,3 +225,38 @@ def test_fuzz_regressions(D):
             r = b.result(0)
             assert r["status"] == rc and r["saved_bits"] == saved and b.output(0) == (want if rc == 0 else a), (name, merge)
             b.close()
+
+
+def test_persistent_wait_expiry_is_recovered_by_the_level_executor(D, monkeypatch):
+    """A wait of the persistent executor that gives up (D4G_SPIN_LIMIT=0: any wait whose slot is not there yet) is not an
+    error: nothing is selected, the round runs again with the level executor; output == oracle, fallback counted."""
+    monkeypatch.setenv("D4G_EXEC", "persistent")
+    monkeypatch.setenv("D4G_SPIN_LIMIT", "-1")
+    a = synth.make_stream(300000, 4)
+    for merge in (False, True):
+        b = D.Batch([a]).run(merge)
+        rc, want, saved, _, _ = O.optimise(a, merge)
+        assert b.output(0) == want and b.result(0)["saved_bits"] == saved
+        assert b.stats()["persist_fallbacks"] > 0
+        b.close()
+
+
+def test_config5_mix_through_the_sharded_path(D):
+    """BASELINE config 5 at reduced size on the real library: 14 streams of the PNG-IDAT-like / gzip-member mix
+    (synth.mixed_spec, sizes divided by 32 -> 32-512 KiB) through shard.optimise_sharded with one rank, merge on (the CLI
+    default); every output == the optimiser oracle's, the totals add up."""
+    from deft4j_amd import shard
+    items = []
+    for i in range(14):
+        kind, n = synth.mixed_spec(i)
+        n = max(32 << 10, n // 32)
+        raw = synth.pngidat(n, 0x1DA7 + i) if kind == "idat" else synth.reptext(n, 0xD4F7 + i)
+        items.append((kind, raw, synth.deflate9(raw)))
+    assert {k for k, _, _ in items} == {"idat", "gzip"}
+    streams = [it[2] for it in items]
+    total, outs, saved = shard.optimise_sharded([len(s) for s in streams], lambda i: streams[i], True, lambda ss: D.Batch(ss), batch_bytes=1 << 20)
+    want = _oracle_many(streams, True)
+    assert total == sum(w[2] for w in want if w[0] == 0)
+    for i, (s, o, w) in enumerate(zip(streams, outs, want)):
+        assert o == (w[1] if w[0] == 0 else None), (i, items[i][0], len(items[i][1]))
+        assert zlib.decompress(o if o is not None else s, -15) == items[i][1]

@@ -108,3 +108,23 @@ def test_batch_of_members_through_mode_zopfli_extensive():
     outs = cu.compress_many(datas)
     for d, o, w in zip(datas, outs, cu.last_winner):
         assert (o, w) == OC.compress(d, True, D.MODE_ZOPFLI_EXTENSIVE, 4), len(d)
+
+
+def test_change_point_pool_grows_instead_of_failing(monkeypatch):
+    """a valid input whose positions have many record-setting matches (groups S[:200], S[:199], ... S[:3], S)
+    ran the change-point pool out and failed the whole batch.  The match kernels now run again with a larger pool: the
+    246 KB input of the report round-trips at the pool's natural size, a small one equals the oracle with the pool forced tiny."""
+    S = synth.reptext(200, 1)
+    group = b"".join(S[:k] for k in range(200, 2, -1)) + S
+    big = group * 12
+    assert len(big) > 240000
+    out = D.zopfli_streams([big, S], 2, Z.SPLIT_FIRST, 15, 8 << 20)
+    assert zlib.decompress(out[0], -15) == big and zlib.decompress(out[1], -15) == S
+    monkeypatch.setenv("D4G_ZF_POOL_WORDS", "256")
+    small = group[:6000]
+    for split in (Z.SPLIT_FIRST, Z.SPLIT_LAST):
+        assert D.zopfli_streams([small], 2, split, 15, 8 << 20)[0] == Z.deflate(small, 2, split, 15, 8 << 20, Z.LOG_PORTABLE)
+    # a whole recompress call survives as well (the candidate list is complete)
+    cu = D.CompressionUtil(D.MODE_ZOPFLI, 1, True)
+    o = cu.compress_many([small])[0]
+    assert zlib.decompress(o, -15) == small

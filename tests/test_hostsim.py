@@ -311,3 +311,35 @@ def test_gzip_file_through_mode_cheap_in_the_emulator(sim):
     want = OC.recompress(payload, True)
     assert want["recompress_saved"] > 0 and out[10:-8] == want["out"]
     assert lines[-1] == "Saved %d bits with recompression" % want["recompress_saved"]
+
+
+def test_persistent_wait_expiry_is_recovered_by_the_level_executor(sim, monkeypatch):
+    """A wait of the persistent executor that gives up (D4G_SPIN_LIMIT=-1: every one does) is not an error: nothing is
+    selected, the round runs again with the level executor, the output is the oracle's and the fallback is counted."""
+    monkeypatch.setenv("D4G_EXEC", "persistent")
+    monkeypatch.setenv("D4G_SPIN_LIMIT", "-1")
+    D, L = sim
+    a = synth.make_stream(9000, 4)
+    for merge in (False, True):
+        b = D.Batch([a], lib=L).run(merge)
+        rc, want, saved, _, _ = O.optimise(a, merge)
+        assert b.output(0) == want and b.result(0)["saved_bits"] == saved
+        assert b.stats()["persist_fallbacks"] > 0
+        b.close()
+
+
+def test_zopfli_change_point_pool_grows_instead_of_failing(sim, monkeypatch):
+    """Positions with many record-setting matches (nearest = shortest) overflow the change-point pool's first size:
+    the match kernels are run again with a larger pool and the streams are the oracle's."""
+    import zopf_lib as ZF
+    monkeypatch.setenv("D4G_ZF_POOL_WORDS", "64")
+    D, L = sim
+    S = synth.reptext(70, 3)
+    ladder = b"".join(S[:k] for k in range(60, 2, -1)) + S
+    data = ladder * 2
+    for split in (ZF.SPLIT_FIRST, ZF.SPLIT_NONE):
+        out = D.zopfli_streams([data, S], 2, split, 15, 8 << 20, lib=L)
+        assert out[0] == ZF.deflate(data, 2, split, 15, 8 << 20, ZF.LOG_PORTABLE)
+        assert out[1] == ZF.deflate(S, 2, split, 15, 8 << 20, ZF.LOG_PORTABLE)
+    # unlimited splitting (blocksplittingmax 0): more split points than the old fixed buffer is no longer an error either
+    assert D.zopfli_streams([data], 1, ZF.SPLIT_FIRST, 0, 8 << 20, lib=L)[0] == ZF.deflate(data, 1, ZF.SPLIT_FIRST, 0, 8 << 20, ZF.LOG_PORTABLE)
