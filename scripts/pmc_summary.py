@@ -25,7 +25,7 @@ def fold(path, name):
 out = {"FETCH_SIZE": fold(sys.argv[1], "FETCH_SIZE"), "WRITE_SIZE": fold(sys.argv[2], "WRITE_SIZE"),
        "note": "one bench.py step (--steps 1 --warmup 0, D4G_LANES=1); KB as reported by rocprofv3; corrected_per_dispatch_MB = x2 for the "
                "kernels whose loads are 16 bytes per lane and contiguous (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of those)"}
-for k in ("k_exec_state_ops", "k_jump_streams", "k_lz_parse", "k_write"):   # 16-byte-per-lane streaming loads (records / uint4 entries / window staging)
+for k in ("k_exec_state_ops", "k_search_fused", "k_jump_streams", "k_lz_parse", "k_write"):   # 16-byte-per-lane streaming loads (records / uint4 entries / window staging)
     if k in out["FETCH_SIZE"]:
         out["FETCH_SIZE"][k]["corrected_per_dispatch_MB"] = round(2 * out["FETCH_SIZE"][k]["per_dispatch_MB"], 3)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
