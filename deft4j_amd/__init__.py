@@ -51,7 +51,8 @@ EXPORTS = ["d4g_init", "d4g_shutdown", "d4g_last_error", "d4g_batch_create", "d4
            "d4g_batch_copy_output", "d4g_batch_copy_decoded", "d4g_batch_checksums", "d4g_batch_parse", "d4g_batch_stats", "d4g_batch_destroy", "d4g_optimise_streams",
            "d4g_size_bits_fallback", "d4g_inflate", "d4g_free", "d4g_batch_create_encode", "d4g_batch_run_encode", "d4g_deflate_streams",
            "d4g_compress", "d4g_recompress_streams", "d4g_batch_run_recompress", "d4g_batch_recompress_result", "d4g_zopfli_streams",
-           "d4g_debug_zopfli_table", "d4g_debug_zopfli_code_lengths"]
+           "d4g_debug_zopfli_table", "d4g_debug_zopfli_code_lengths", "d4g_init_devices", "d4g_device_count", "d4g_set_device",
+           "d4g_batch_create_on", "d4g_optimise_streams_sharded"]
 
 
 def load_library(path=None):
@@ -128,6 +129,15 @@ def load_library(path=None):
     L.d4g_recompress_streams.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]
+    L.d4g_init_devices.restype = ctypes.c_int
+    L.d4g_init_devices.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.d4g_device_count.restype = ctypes.c_int
+    L.d4g_set_device.restype = ctypes.c_int
+    L.d4g_set_device.argtypes = [ctypes.c_int]
+    L.d4g_batch_create_on.restype = ctypes.c_void_p
+    L.d4g_batch_create_on.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.d4g_optimise_streams_sharded.restype = ctypes.c_int
+    L.d4g_optimise_streams_sharded.argtypes = L.d4g_optimise_streams.argtypes
     if path is None:
         _lib = L
     return L
@@ -147,6 +157,44 @@ def init(device_index=None, lib=None):
     return L
 
 
+def init_devices(devices, lib=None):
+    """d4g_init_devices: one process driving several GPUs — context k = devices[k] (a device may appear twice)."""
+    global _ready
+    L = lib or load_library()
+    arr = (ctypes.c_int * len(devices))(*devices)
+    rc = L.d4g_init_devices(len(devices), arr)
+    if rc != 0:
+        raise RuntimeError("d4g_init_devices(%r) failed: %s" % (list(devices), L.d4g_last_error().decode()))
+    if lib is None:
+        _ready = True
+    return L
+
+
+def optimise_streams_sharded(streams, merge_blocks=True, lib=None):
+    """d4g_optimise_streams_sharded: the list over every initialised context.  -> (outputs, saved_bits, status) with
+    outputs[i] = None when stream i keeps its original bytes."""
+    L = lib or _need()
+    n = len(streams)
+    keep = [bytes(s) for s in streams]
+    arr = (ctypes.c_char_p * n)(*keep)
+    lens = (ctypes.c_size_t * n)(*[len(s) for s in keep])
+    out = (ctypes.c_void_p * n)()
+    olen = (ctypes.c_size_t * n)()
+    saved = (ctypes.c_int64 * n)()
+    status = (ctypes.c_int32 * n)()
+    rc = L.d4g_optimise_streams_sharded(n, arr, lens, 1 if merge_blocks else 0, out, olen, saved, status)
+    if rc != 0:
+        raise RuntimeError("d4g_optimise_streams_sharded: " + L.d4g_last_error().decode())
+    res = []
+    for i in range(n):
+        if out[i]:
+            res.append(ctypes.string_at(out[i], olen[i]))
+            L.d4g_free(out[i])
+        else:
+            res.append(None)
+    return res, list(saved), list(status)
+
+
 def _need():
     if not _ready:
         init()
@@ -156,13 +204,16 @@ def _need():
 class Batch:
     """A list of independent raw DEFLATE streams resident in HBM (d4g_batch_*)."""
 
-    def __init__(self, streams, lib=None):
+    def __init__(self, streams, lib=None, context=None):
         self.L = lib or _need()
         self.n = len(streams)
         self._keep = [bytes(s) for s in streams]
         arr = (ctypes.c_char_p * self.n)(*self._keep)
         lens = (ctypes.c_size_t * self.n)(*[len(s) for s in self._keep])
-        self.h = self.L.d4g_batch_create(self.n, arr, lens)
+        if context is None:
+            self.h = self.L.d4g_batch_create(self.n, arr, lens)
+        else:   # d4g_batch_create_on: the batch lives on that context (device) whichever thread calls with it
+            self.h = self.L.d4g_batch_create_on(context, self.n, arr, lens)
         if not self.h:
             raise RuntimeError("d4g_batch_create: " + self.L.d4g_last_error().decode())
 

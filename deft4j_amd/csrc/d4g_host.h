@@ -494,9 +494,9 @@ struct Engine {  // per-process device objects shared by all batches
         ready = true;
     }
 };
-inline Engine& engine() {
-    static Engine e;
-    return e;
+inline Engine& engine() {   // one per context (d4g_rt.h): the programs live in that device's memory
+    static Engine e[RT_MAX_CTX];
+    return e[rt_ctx()];
 }
 
 // host view of one block of a stream

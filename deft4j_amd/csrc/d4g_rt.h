@@ -28,12 +28,38 @@
 // HIP streams, so independent batches overlap on the device instead of queueing behind one library-wide lock.
 inline bool& rt_low_priority_thread() { thread_local bool v = false; return v; }   // set before the thread's first runtime call
 struct RtGlobals;
-struct RtProcess {
+// Device memory comes from a small caching pool: hipMalloc / hipFree cost milliseconds for the buffers a batch
+// needs (and vary a lot from host to host), so freed blocks are kept by size class and handed out again.
+// Callers free a block only after the work that used it has completed (they synchronise first), as hipFree's
+// implicit device synchronisation used to guarantee.
+struct RtPool {
+    std::multimap<size_t, void*> freeBlocks;      // capacity -> block
+    std::unordered_map<void*, size_t> capacity;   // every block the pool handed out or holds
+    size_t heldBytes = 0;                         // bytes sitting in freeBlocks
+    size_t maxHeldBytes = (size_t)64 << 30;       // D4G_POOL_MAX_MB overrides
+    static size_t size_class(size_t n) {          // 1/8-octave steps: at most 12.5 % slack
+        if (n < 4096) return 4096;
+        int hb = 63 - __builtin_clzll((unsigned long long)n);
+        size_t step = (size_t)1 << (hb - 3);
+        return (n + step - 1) & ~(step - 1);
+    }
+};
+// One process may drive several GPUs (a JVM is one process: CompressionUtil's pool, C/CompressionUtil.java:99-117, fans
+// streams over the devices of a node): a *context* = one device with its own memory pool, its own copy of the search
+// programs and, per host thread, its own streams.  The same device may back two contexts (tests on a one-GPU box).  The
+// context a host thread works on is thread-local: the C ABI sets it from the batch / the caller's choice at every entry.
+#define RT_MAX_CTX 16
+struct RtContext {
     int device = -1;
     bool ready = false;
+    RtPool pool;
+};
+struct RtProcess {
+    RtContext ctx[RT_MAX_CTX];
     std::mutex mu;
     std::vector<RtGlobals*> threads;
 };
+inline int& rt_ctx() { thread_local int c = 0; return c; }
 inline RtProcess& rtp() {
     static RtProcess p;
     return p;
@@ -46,9 +72,10 @@ struct RtGlobals {
     hipStream_t b[RT_MAX_LANES] = {nullptr};
     int cur = 0;
     bool made = false;
+    int ctxIdx;
     int& device;
     bool& ready;
-    RtGlobals() : device(rtp().device), ready(rtp().ready) {
+    explicit RtGlobals(int c) : ctxIdx(c), device(rtp().ctx[c].device), ready(rtp().ctx[c].ready) {
         std::lock_guard<std::mutex> lk(rtp().mu);
         rtp().threads.push_back(this);
     }
@@ -97,30 +124,17 @@ struct RtGlobals {
     hipStream_t& stream_ref() { make_lane(cur); return a[cur]; }
 };
 inline RtGlobals& rt() {
-    thread_local RtGlobals g;
-    g.ensure();
-    return g;
+    struct PerThread {
+        RtGlobals* g[RT_MAX_CTX] = {nullptr};
+        ~PerThread() { for (RtGlobals* p : g) delete p; }
+    };
+    thread_local PerThread t;
+    const int c = rt_ctx();
+    if (!t.g[c]) t.g[c] = new RtGlobals(c);
+    t.g[c]->ensure();
+    return *t.g[c];
 }
-// Device memory comes from a small caching pool: hipMalloc / hipFree cost milliseconds for the buffers a batch
-// needs (and vary a lot from host to host), so freed blocks are kept by size class and handed out again.
-// Callers free a block only after the work that used it has completed (they synchronise first), as hipFree's
-// implicit device synchronisation used to guarantee.
-struct RtPool {
-    std::multimap<size_t, void*> freeBlocks;      // capacity -> block
-    std::unordered_map<void*, size_t> capacity;   // every block the pool handed out or holds
-    size_t heldBytes = 0;                         // bytes sitting in freeBlocks
-    size_t maxHeldBytes = (size_t)64 << 30;       // D4G_POOL_MAX_MB overrides
-    static size_t size_class(size_t n) {          // 1/8-octave steps: at most 12.5 % slack
-        if (n < 4096) return 4096;
-        int hb = 63 - __builtin_clzll((unsigned long long)n);
-        size_t step = (size_t)1 << (hb - 3);
-        return (n + step - 1) & ~(step - 1);
-    }
-};
-inline RtPool& rt_pool() {
-    static RtPool p;
-    return p;
-}
+inline RtPool& rt_pool() { return rtp().ctx[rt_ctx()].pool; }
 inline void* rt_malloc(size_t n) {
     std::lock_guard<std::mutex> lk(rtp().mu);
     RtPool& P = rt_pool();

@@ -11,6 +11,7 @@
 using namespace d4g;
 
 struct d4g_batch {
+    int ctx = 0;   // the context (device) the batch lives on: every call with the batch works there
     Batch impl;
     std::unique_ptr<LzFront> lz;   // set for batches made by d4g_batch_create_encode
     // d4g_batch_run_recompress: the re-optimised winners of the recompression (its own copy of their bytes) and which streams took them
@@ -44,6 +45,18 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 bool ready() { return rt().ready; }
+// The context of the calling thread for this call: the batch's, or — for calls that create batches / one-shot calls — the
+// thread's choice (d4g_set_device; context 0 unless it chose).
+thread_local int g_tlsCtx = 0;
+int g_nCtx = 0;   // contexts initialised (d4g_init: 1)
+void enter_ctx(const d4g_batch* b) { rt_ctx() = b ? b->ctx : g_tlsCtx; }
+bool rtp_ctx_ready(int k) {
+#ifdef D4G_HOSTSIM
+    return k < g_nCtx;
+#else
+    return rtp().ctx[k].ready;
+#endif
+}
 // HIP's current device is per thread: CompressionUtil's pool threads (and any rank with device != 0) must bind
 // the library's device before allocating or launching.  Called at the top of every entry point (d4g_init / d4g_shutdown hold g_mu;
 // the others run concurrently, each on its calling thread).
@@ -58,56 +71,100 @@ extern "C" {
 
 const char* d4g_last_error(void) { return g_err.c_str(); }
 
+// one context: device + memory pool + programs (caller holds g_mu)
+static int init_ctx(int ctx, int device_index) {
+    rt_ctx() = ctx;
+#ifndef D4G_HOSTSIM
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(D4G_ERR_NODEVICE, "no HIP device available (libdeft4g has no CPU fallback)");
+    if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
+    if (rt().ready && rt().device != device_index)
+        return fail(D4G_ERR_ARG, "already initialised on device " + std::to_string(rt().device) + ": call d4g_shutdown() before selecting another device");
+    RT_CHECK(hipSetDevice(device_index));
+    rt().device = device_index;
+    if (const char* mb = getenv("D4G_POOL_MAX_MB")) rt_pool().maxHeldBytes = (size_t)atoll(mb) << 20;
+#endif
+    rt().ready = true;
+    (void)rt();           // this thread's streams
+    engine().init();
+    return D4G_OK;
+}
+
 int d4g_init(int device_index) {
     std::lock_guard<std::mutex> lk(g_mu);
     try {
-#ifndef D4G_HOSTSIM
-        int n = 0;
-        hipError_t e = hipGetDeviceCount(&n);
-        if (e != hipSuccess || n <= 0) return fail(D4G_ERR_NODEVICE, "no HIP device available (libdeft4g has no CPU fallback)");
-        if (device_index < 0 || device_index >= n) return fail(D4G_ERR_ARG, "device index out of range");
-        if (rt().ready && rt().device != device_index)
-            return fail(D4G_ERR_ARG, "already initialised on device " + std::to_string(rt().device) + ": call d4g_shutdown() before selecting another device");
-        RT_CHECK(hipSetDevice(device_index));
-        rt().device = device_index;
-        if (const char* mb = getenv("D4G_POOL_MAX_MB")) rt_pool().maxHeldBytes = (size_t)atoll(mb) << 20;
-#endif
-        rt().ready = true;
-        (void)rt();           // this thread's streams
-        engine().init();
-        return D4G_OK;
+        int rc = init_ctx(0, device_index);
+        if (rc == D4G_OK && g_nCtx < 1) g_nCtx = 1;
+        rt_ctx() = g_tlsCtx;
+        return rc;
     } catch (const std::exception& ex) {
         return fail(D4G_ERR_RUNTIME, ex.what());
     }
 }
 
+int d4g_init_devices(int n, const int* device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (n < 1 || n > RT_MAX_CTX || !device_index) return fail(D4G_ERR_ARG, "1 to 16 contexts");
+    try {
+        for (int k = 0; k < n; k++) {
+            int rc = init_ctx(k, device_index[k]);
+            if (rc != D4G_OK) { rt_ctx() = g_tlsCtx; return rc; }
+        }
+        g_nCtx = std::max(g_nCtx, n);
+        rt_ctx() = g_tlsCtx;
+        return D4G_OK;
+    } catch (const std::exception& ex) {
+        rt_ctx() = g_tlsCtx;
+        return fail(D4G_ERR_RUNTIME, ex.what());
+    }
+}
+
+int d4g_device_count(void) { return g_nCtx; }
+
+int d4g_set_device(int context) {
+    if (context < 0 || context >= RT_MAX_CTX || !rtp_ctx_ready(context)) return fail(D4G_ERR_ARG, "no such context (d4g_init_devices)");
+    g_tlsCtx = context;
+    rt_ctx() = context;
+    return D4G_OK;
+}
+
 void d4g_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!rt().ready) return;
-    try {
-        bind_device();
-        rt_sync_all();
-        engine().release();
+    for (int k = 0; k < RT_MAX_CTX; k++) {
+        rt_ctx() = k;
+        if (!rt().ready) continue;
+        try {
+            bind_device();
+            rt_sync_all();
+            engine().release();
 #ifndef D4G_HOSTSIM
-        rt_pool_release();
-        {   // every host thread's streams (no batch may be running: shutdown is exclusive by contract)
-            std::vector<RtGlobals*> all;
-            { std::lock_guard<std::mutex> lk2(rtp().mu); all = rtp().threads; }
-            for (RtGlobals* g : all) g->destroy_streams();
-        }
-        rt().device = -1;
+            rt_pool_release();
+            {   // every host thread's streams of this context (no batch may be running: shutdown is exclusive by contract)
+                std::vector<RtGlobals*> all;
+                { std::lock_guard<std::mutex> lk2(rtp().mu); all = rtp().threads; }
+                for (RtGlobals* g : all)
+                    if (g->ctxIdx == k) g->destroy_streams();
+            }
+            rt().device = -1;
 #endif
-    } catch (const std::exception&) {
+        } catch (const std::exception&) {
+        }
+        rt().ready = false;
     }
-    rt().ready = false;
+    g_nCtx = 0;
+    g_tlsCtx = 0;
+    rt_ctx() = 0;
 }
 
 d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len) {
+    enter_ctx(nullptr);
     D4G_API_LOCK();
     if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
     try {
         bind_device();
         std::unique_ptr<d4g_batch> b(new d4g_batch());
+        b->ctx = rt_ctx();
         b->impl.create(n, in, in_len);
         return b.release();
     } catch (const std::exception& ex) {
@@ -117,6 +174,7 @@ d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in
 }
 
 int d4g_batch_run(d4g_batch* b, int merge_blocks) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
@@ -132,6 +190,7 @@ int d4g_batch_run(d4g_batch* b, int merge_blocks) {
 
 d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const size_t* raw_len, size_t n_out,
                                    const d4g_encoder_spec* spec) {
+    enter_ctx(nullptr);
     D4G_API_LOCK();
     if (!ready()) { fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded"); return nullptr; }
     if ((n_in && (!raw || !raw_len)) || (n_out && !spec)) { fail(D4G_ERR_ARG, "null argument"); return nullptr; }
@@ -139,6 +198,7 @@ d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const
         bind_device();
         static_assert(sizeof(LzSpec) == sizeof(d4g_encoder_spec), "spec layout");
         std::unique_ptr<d4g_batch> b(new d4g_batch());
+        b->ctx = rt_ctx();
         b->lz.reset(new LzFront(b->impl));
         b->lz->create(n_in, raw, raw_len, n_out, (const LzSpec*)spec);
         return b.release();
@@ -149,6 +209,7 @@ d4g_batch* d4g_batch_create_encode(size_t n_in, const uint8_t* const* raw, const
 }
 
 int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b || !b->lz) return fail(D4G_ERR_ARG, "not an encoder batch");
@@ -163,6 +224,7 @@ int d4g_batch_run_encode(d4g_batch* b, int optimise, int merge_blocks) {
 
 int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int encoder, int strategy, uint8_t** out,
                         size_t* out_len) {
+    enter_ctx(nullptr);
     if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; }
     std::vector<d4g_encoder_spec> sp(n);
@@ -188,6 +250,7 @@ int d4g_deflate_streams(size_t n, const uint8_t* const* raw, const size_t* raw_l
 
 int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* saved_bits, size_t* out_len, size_t* consumed,
                             int64_t* size_bits_in) {
+    enter_ctx(b);
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     const HStream& s = b->impl.streams[i];
     const Batch* owner = nullptr;
@@ -203,6 +266,7 @@ int d4g_batch_stream_result(d4g_batch* b, size_t i, int32_t* status, int64_t* sa
 }
 
 int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
@@ -220,6 +284,7 @@ int d4g_batch_copy_output(d4g_batch* b, size_t i, uint8_t* dst, size_t cap) {
 }
 
 int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, size_t* len) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     const HStream& s = b->impl.streams[i];
@@ -237,6 +302,7 @@ int d4g_batch_copy_decoded(d4g_batch* b, size_t i, uint8_t* dst, size_t cap, siz
 }
 
 int d4g_batch_parse(d4g_batch* b) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b) return fail(D4G_ERR_ARG, "null batch");
@@ -254,6 +320,7 @@ int d4g_batch_parse(d4g_batch* b) {
 }
 
 int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler32, int64_t* isize) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (b->impl.streams[i].status != 0) return fail(D4G_ERR_ARG, "stream did not parse");
@@ -271,12 +338,14 @@ int d4g_batch_checksums(d4g_batch* b, size_t i, uint32_t* crc32, uint32_t* adler
 }
 
 int d4g_batch_stats(d4g_batch* b, d4g_stats* st) {
+    enter_ctx(b);
     if (!b || !st) return fail(D4G_ERR_ARG, "null argument");
     *st = b->impl.stats;
     return D4G_OK;
 }
 
 void d4g_batch_destroy(d4g_batch* b) {
+    enter_ctx(b);
     D4G_API_LOCK();
     try { bind_device(); } catch (const std::exception&) {}
     delete b;
@@ -284,6 +353,7 @@ void d4g_batch_destroy(d4g_batch* b) {
 
 int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
                          size_t* out_len, int64_t* saved_bits, int32_t* status) {
+    enter_ctx(nullptr);
     if (n && (!in || !in_len || !out || !out_len || !status)) return fail(D4G_ERR_ARG, "null argument");
     // every result slot is defined whatever happens below: "keep the original" until a stream is known to have changed
     for (size_t i = 0; i < n; i++) {
@@ -324,7 +394,75 @@ int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_le
     return rc;
 }
 
+d4g_batch* d4g_batch_create_on(int context, size_t n, const uint8_t* const* in, const size_t* in_len) {
+    if (context < 0 || context >= RT_MAX_CTX || !rtp_ctx_ready(context)) { fail(D4G_ERR_ARG, "no such context (d4g_init_devices)"); return nullptr; }
+    const int keep = g_tlsCtx;
+    g_tlsCtx = context;
+    d4g_batch* b = d4g_batch_create(n, in, in_len);
+    g_tlsCtx = keep;
+    return b;
+}
+
+// DeflateFilesContainer.optimise(List<DeflateStream>, boolean) over every initialised context (K/DeflateFilesContainer.java:18-43:
+// the streams are independent): longest-processing-time-first partition by compressed size, one host thread and one batch per
+// context, no exchange between the devices; the outputs are gathered in the caller's arrays (host memory) in stream order.
+int d4g_optimise_streams_sharded(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
+                                 size_t* out_len, int64_t* saved_bits, int32_t* status) {
+    enter_ctx(nullptr);
+    const int nc = g_nCtx;
+    if (nc <= 1) return d4g_optimise_streams(n, in, in_len, merge_blocks, out, out_len, saved_bits, status);
+    if (n && (!in || !in_len || !out || !out_len || !status)) return fail(D4G_ERR_ARG, "null argument");
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return in_len[a] > in_len[b]; });
+    std::vector<std::vector<size_t>> shard(nc);
+    std::vector<unsigned long long> load(nc, 0);
+    for (size_t i : order) {
+        int r = 0;
+        for (int k = 1; k < nc; k++) if (load[k] < load[r]) r = k;
+        shard[r].push_back(i);
+        load[r] += in_len[i];
+    }
+    std::vector<int> rcs(nc, D4G_OK);
+    std::vector<std::string> errs(nc);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nc; k++) {
+        std::sort(shard[k].begin(), shard[k].end());
+        th.emplace_back([&, k]() {
+            g_tlsCtx = k;   // this thread works on context k
+            const std::vector<size_t>& idx = shard[k];
+            const size_t m = idx.size();
+            std::vector<const uint8_t*> sin(m);
+            std::vector<size_t> slen(m), solen(m);
+            std::vector<uint8_t*> sout(m);
+            std::vector<int64_t> ssaved(m);
+            std::vector<int32_t> sst(m);
+            for (size_t j = 0; j < m; j++) { sin[j] = in[idx[j]]; slen[j] = in_len[idx[j]]; }
+            rcs[k] = d4g_optimise_streams(m, sin.data(), slen.data(), merge_blocks, sout.data(), solen.data(), ssaved.data(), sst.data());
+            if (rcs[k] != D4G_OK) errs[k] = g_err;
+            for (size_t j = 0; j < m; j++) {
+                out[idx[j]] = sout[j]; out_len[idx[j]] = solen[j]; status[idx[j]] = sst[j];
+                if (saved_bits) saved_bits[idx[j]] = ssaved[j];
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    int rc = D4G_OK;
+    for (int k = 0; k < nc; k++)
+        if (rcs[k] != D4G_OK) { rc = rcs[k]; g_err = errs[k]; }
+    if (rc != D4G_OK)   // all-or-nothing, like the single-device call
+        for (size_t i = 0; i < n; i++) {
+            free(out[i]);
+            out[i] = nullptr;
+            out_len[i] = 0;
+            status[i] = D4G_STREAM_UNCHANGED;
+            if (saved_bits) saved_bits[i] = 0;
+        }
+    return rc;
+}
+
 int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
+    enter_ctx(nullptr);
     if (!in || !bits) return fail(D4G_ERR_ARG, "null argument");
     const uint8_t* ins[1] = {in};
     size_t lens[1] = {len};
@@ -349,6 +487,7 @@ int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits) {
 }
 
 int d4g_inflate(const uint8_t* in, size_t len, uint8_t** out, size_t* out_len, size_t* consumed, int32_t* status) {
+    enter_ctx(nullptr);
     if (!in || !out || !out_len || !status) return fail(D4G_ERR_ARG, "null argument");
     const uint8_t* ins[1] = {in};
     size_t lens[1] = {len};
@@ -404,6 +543,7 @@ struct ZfUpload {
 
 int d4g_zopfli_streams(size_t n, const uint8_t* const* raw, const size_t* raw_len, int iterations, int splitting, int max_blocks,
                        size_t master_block, uint8_t** out, size_t* out_len) {
+    enter_ctx(nullptr);
     if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; }
     if (iterations < 1 || splitting < 0 || splitting > 2 || max_blocks < 0 || master_block > ((size_t)8 << 20)) return fail(D4G_ERR_ARG, "bad zopfli options");
@@ -438,6 +578,7 @@ int d4g_zopfli_streams(size_t n, const uint8_t* const* raw, const size_t* raw_le
 }
 
 int d4g_debug_zopfli_table(const uint8_t* raw, size_t n, size_t end, uint16_t* len16, uint16_t* dist16, uint16_t* sublen) {
+    enter_ctx(nullptr);
     if (!raw || !len16 || !dist16) return fail(D4G_ERR_ARG, "null argument");
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
@@ -494,6 +635,7 @@ __global__ void __launch_bounds__(64) k_zf_debug_code_lengths(const uint32_t* fr
 }
 
 int d4g_debug_zopfli_code_lengths(const uint32_t* freq, int n, int maxbits, uint32_t* lengths) {
+    enter_ctx(nullptr);
     if (!freq || !lengths || n < 1 || n > ZF_NUM_LL || maxbits < 1 || maxbits > 15) return fail(D4G_ERR_ARG, "bad argument");
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
@@ -580,6 +722,7 @@ void add_stats(d4g_stats& a, const d4g_stats& o) {
 std::unique_ptr<d4g_batch> encode_batch(size_t n, const uint8_t* const* raw, const size_t* len, bool fromDevice, const std::vector<LzSpec>& specs,
                                         bool merge) {
     std::unique_ptr<d4g_batch> e(new d4g_batch());
+    e->ctx = rt_ctx();
     e->lz.reset(new LzFront(e->impl));
     e->lz->create(n, raw, len, specs.size(), specs.data(), fromDevice);
     e->lz->run(true, merge);
@@ -600,6 +743,7 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
     for (size_t i = 0; i < n; i++)
         for (int k : lzIdx) { LzSpec s = list[k]; s.input = (int32_t)i; specs.push_back(s); }
     std::unique_ptr<d4g_batch> e1(new d4g_batch());
+    e1->ctx = rt_ctx();
     e1->lz.reset(new LzFront(e1->impl));
     e1->lz->create(n, raw + i0, len + i0, specs.size(), specs.data(), fromDevice);
     // stage 3 starts here, on its own host thread (its own HIP streams): the Zopfli compressors' outputs, encoded on the device
@@ -611,8 +755,10 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
         double ms = 0, msTable = 0, msSplit = 0, msSqueeze = 0, msEmit = 0;
         int64_t blocks = 0, posIter = 0, outputs = 0;
     } Z;
+    const int parentCtx = rt_ctx();
     auto zopfli_stage = [&]() {
         try {
+            rt_ctx() = parentCtx;   // (a new host thread starts on context 0)
 #ifndef D4G_HOSTSIM
             rt_low_priority_thread() = true;      // this thread's streams carry kernels that run for minutes (d4g_rt.h)
 #endif
@@ -633,6 +779,7 @@ void compress_group(CompressRun& R, size_t i0, size_t i1, const uint8_t* const* 
             std::vector<size_t> sl(zs.size());
             for (size_t q = 0; q < zs.size(); q++) { sp[q] = (const uint8_t*)zf.outWords[q]; sl[q] = (size_t)((zf.outBits[q] + 7) / 8); }
             Z.e3.reset(new d4g_batch());
+            Z.e3->ctx = rt_ctx();
             Z.e3->impl.create(zs.size(), sp.data(), sl.data(), true);
             Z.ms = now_ms() - tz;
             Z.e3->impl.run(merge);
@@ -793,6 +940,7 @@ extern "C" {
 
 int d4g_compress(size_t n, const uint8_t* const* raw, const size_t* raw_len, int mode, int iter, int merge_blocks, uint8_t** out,
                  size_t* out_len, int32_t* winner) {
+    enter_ctx(nullptr);
     if (n && (!raw || !raw_len || !out || !out_len)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) { out[i] = nullptr; out_len[i] = 0; if (winner) winner[i] = -1; }
     D4G_API_LOCK();
@@ -883,6 +1031,7 @@ static void run_recompress_locked(d4g_batch* b, int mode, int iter, bool merge) 
 }
 
 int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks) {
+    enter_ctx(b);
     D4G_API_LOCK();
     if (!ready()) return fail(D4G_ERR_NODEVICE, "d4g_init has not succeeded");
     if (!b || b->lz) return fail(D4G_ERR_ARG, "not a batch of deflate streams");
@@ -899,6 +1048,7 @@ int d4g_batch_run_recompress(d4g_batch* b, int mode, int iter, int merge_blocks)
 }
 
 int d4g_batch_recompress_result(d4g_batch* b, size_t i, int32_t* grafted, int64_t* recompress_saved) {
+    enter_ctx(b);
     if (!b || i >= b->impl.streams.size()) return fail(D4G_ERR_ARG, "bad stream index");
     if (grafted) *grafted = i < b->graft.size() ? b->graft[i] : 0;
     if (recompress_saved) *recompress_saved = i < b->recompSaved.size() ? b->recompSaved[i] : 0;
@@ -907,6 +1057,7 @@ int d4g_batch_recompress_result(d4g_batch* b, size_t i, int32_t* grafted, int64_
 
 int d4g_recompress_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int mode, int iter, int merge_blocks,
                            uint8_t** out, size_t* out_len, int64_t* saved_bits, int64_t* recompress_saved, int32_t* status) {
+    enter_ctx(nullptr);
     if (n && (!in || !in_len || !out || !out_len || !status)) return fail(D4G_ERR_ARG, "null argument");
     for (size_t i = 0; i < n; i++) {
         out[i] = nullptr; out_len[i] = 0; status[i] = D4G_STREAM_UNCHANGED;
@@ -967,6 +1118,7 @@ long long d4g_test_pack_kinds(void) {
 
 // dev tool: the fused executor's accounting (collected while D4G_FUSED_STATS is set; see k_search_fused); read and cleared
 int d4g_debug_fused_stats(long long* out64) {
+    enter_ctx(nullptr);
     D4G_API_LOCK();
     d4g::engine().init();
     rt_sync_all();
@@ -979,12 +1131,14 @@ int d4g_debug_fused_stats(long long* out64) {
 #ifdef D4G_PROFILE_OPS
 // profiling builds only (scripts/build_profile_lib.sh): cycles and counts per op kind
 int d4g_debug_set_experiment(long long mode) {
+    enter_ctx(nullptr);
     D4G_API_LOCK();
     rt_h2d(engine().dOpStats + 63, &mode, 8);
     rt_sync();
     return 0;
 }
 int d4g_debug_opstats(long long* out64) {
+    enter_ctx(nullptr);
     D4G_API_LOCK();
     rt_d2h(out64, engine().dOpStats, 64 * 8);
     (void)hipMemcpyFromSymbol(out64 + 56, HIP_SYMBOL(d4g_dbg_counters), 7 * 8);

@@ -80,12 +80,22 @@ typedef struct d4g_stats {
  * Fails (D4G_ERR_NODEVICE) when no device is usable. */
 int d4g_init(int device_index);
 void d4g_shutdown(void);
+/* ---- several GPUs in one process (a JVM is one process; CompressionUtil's pool, C/CompressionUtil.java:99-117, and
+ * DeflateFilesContainer.optimise's stream list, K/DeflateFilesContainer.java:18-43, are what fans out over them) ----
+ * A *context* is one device with its own memory pool and programs; context k = device_index[k] (a device may back more than
+ * one context).  d4g_init(d) == context 0 on device d.  A batch lives on the context it was created on and every call with it
+ * works there, from any host thread; calls that create batches (d4g_batch_create, the one-shot calls) use the calling thread's
+ * context: 0 unless the thread chose another with d4g_set_device. */
+int d4g_init_devices(int n, const int* device_index);
+int d4g_device_count(void);                 /* contexts initialised */
+int d4g_set_device(int context);            /* the calling thread's context from now on */
 const char* d4g_last_error(void);
 
 /* ---- batch API: K/DeflateFilesContainer.java:18-43 `optimise(List<DeflateStream>, boolean)` ----
  * Streams are independent.  create() copies the inputs to HBM; run() does all device work
  * (parse -> optimise -> [mergeBlocks] -> write) with inputs and outputs resident in HBM. */
 d4g_batch* d4g_batch_create(size_t n, const uint8_t* const* in, const size_t* in_len);
+d4g_batch* d4g_batch_create_on(int context, size_t n, const uint8_t* const* in, const size_t* in_len);
 int d4g_batch_run(d4g_batch* b, int merge_blocks);
 /* status: D4G_STREAM_*; saved_bits = DeflateStream.optimise(mergeBlocks) (B/deflate/DeflateStream.java:496);
  * out_len = bytes DeflateStream.asBytes() (:652) would return; consumed = input bytes parse() read
@@ -182,6 +192,11 @@ int d4g_recompress_streams(size_t n, const uint8_t* const* in, const size_t* in_
  * D4G_STREAM_CHANGED (else out[i] = NULL and the caller returns its original array). */
 int d4g_optimise_streams(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
                          size_t* out_len, int64_t* saved_bits, int32_t* status);
+/* The same list over every initialised context (d4g_init_devices): partitioned longest-first by compressed size, one host
+ * thread and one device batch per context, no exchange between devices, outputs gathered in the caller's arrays in list order
+ * (the C-level twin of deft4j_amd/shard.py; with one context it is d4g_optimise_streams). */
+int d4g_optimise_streams_sharded(size_t n, const uint8_t* const* in, const size_t* in_len, int merge_blocks, uint8_t** out,
+                                 size_t* out_len, int64_t* saved_bits, int32_t* status);
 /* Deft.getSizeBitsFallback (B/Deft.java:48-54): parsed bit length, or len*8 when the stream does not parse */
 int d4g_size_bits_fallback(const uint8_t* in, size_t len, int64_t* bits);
 /* DeflateStream.parse + getUncompressedData; *consumed = bytes read.  Returns D4G_ERR_ARG-style <0 only on

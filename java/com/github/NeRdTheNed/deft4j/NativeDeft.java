@@ -20,7 +20,19 @@ public final class NativeDeft {
 
     static {
         System.loadLibrary("deft4g_jni");
-        final int rc = init(Integer.getInteger("deft4g.device", 0));
+        // -Ddeft4g.devices=0,1,2,3,4,5,6,7: one context per GPU of the node (a JVM is one process); otherwise the one device
+        final String devs = System.getProperty("deft4g.devices");
+        final int rc;
+        if (devs != null) {
+            final String[] parts = devs.split(",");
+            final int[] ids = new int[parts.length];
+            for (int i = 0; i < parts.length; i++) {
+                ids[i] = Integer.parseInt(parts[i].trim());
+            }
+            rc = initDevices(ids);
+        } else {
+            rc = init(Integer.getInteger("deft4g.device", 0));
+        }
         if (rc != 0) {
             throw new UnsatisfiedLinkError("deft4g: no usable MI355X (d4g_init returned " + rc + "); there is no CPU fallback in the native library");
         }
@@ -30,6 +42,17 @@ public final class NativeDeft {
     }
 
     private static native int init(int device);
+
+    private static native int initDevices(int[] devices);
+
+    /** contexts (GPUs) initialised */
+    public static native int deviceCount();
+
+    /** the calling thread's context from now on: a pool thread per GPU (CompressionUtil's pool) calls this once */
+    public static native int setDevice(int context);
+
+    /** optimiseStreams over every context: the list is split by size, one device batch per GPU, results in list order */
+    public static native byte[][] optimiseStreamsSharded(byte[][] in, boolean mergeBlocks, long[] savedBits, int[] status);
 
     /** status[i]: 0 changed (result[i] holds the new bytes), 1 unchanged, -1 parse error (result[i] == null: keep the original array) */
     public static native byte[][] optimiseStreams(byte[][] in, boolean mergeBlocks, long[] savedBits, int[] status);

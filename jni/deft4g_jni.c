@@ -30,12 +30,16 @@ typedef struct {
 
 static int pin(JNIEnv* e, jobjectArray in, in_list* L) {
     L->n = (*e)->GetArrayLength(e, in);
+    /* one local reference per element stays alive until unpin(): a batch of a thousand members is far beyond the 16 the JVM
+     * guarantees */
+    if ((*e)->EnsureLocalCapacity(e, L->n + 16) != 0) return -1;
     L->arr = calloc((size_t)L->n + 1, sizeof *L->arr);
     L->ptr = calloc((size_t)L->n + 1, sizeof *L->ptr);
     L->len = calloc((size_t)L->n + 1, sizeof *L->len);
     if (!L->arr || !L->ptr || !L->len) return -1;
     for (jsize i = 0; i < L->n; i++) {
         L->arr[i] = (jbyteArray)(*e)->GetObjectArrayElement(e, in, i);
+        if (!L->arr[i]) return -1;                                   /* a null element: NullPointerException territory in the reference too */
         L->len[i] = (size_t)(*e)->GetArrayLength(e, L->arr[i]);
         L->ptr[i] = (const uint8_t*)(*e)->GetByteArrayElements(e, L->arr[i], NULL);
         if (!L->ptr[i]) return -1;
@@ -43,8 +47,10 @@ static int pin(JNIEnv* e, jobjectArray in, in_list* L) {
     return 0;
 }
 static void unpin(JNIEnv* e, in_list* L) {
-    for (jsize i = 0; i < L->n; i++)
+    for (jsize i = 0; i < L->n; i++) {
         if (L->ptr && L->ptr[i]) (*e)->ReleaseByteArrayElements(e, L->arr[i], (jbyte*)L->ptr[i], JNI_ABORT);
+        if (L->arr && L->arr[i]) (*e)->DeleteLocalRef(e, L->arr[i]);
+    }
     free(L->arr); free((void*)L->ptr); free(L->len);
 }
 static void throw_io(JNIEnv* e, const char* what) {
@@ -54,22 +60,48 @@ static void throw_io(JNIEnv* e, const char* what) {
 }
 /* out[i] (NULL entries stay null) -> byte[][]; frees the library buffers */
 static jobjectArray to_java(JNIEnv* e, jsize n, uint8_t** out, const size_t* olen) {
-    jobjectArray res = (*e)->NewObjectArray(e, n, (*e)->FindClass(e, "[B"), NULL);
+    jclass bytes = (*e)->FindClass(e, "[B");
+    jobjectArray res = bytes ? (*e)->NewObjectArray(e, n, bytes, NULL) : NULL;
     for (jsize i = 0; i < n; i++) {
         if (out[i]) {
-            jbyteArray o = (*e)->NewByteArray(e, (jsize)olen[i]);
-            (*e)->SetByteArrayRegion(e, o, 0, (jsize)olen[i], (const jbyte*)out[i]);
-            (*e)->SetObjectArrayElement(e, res, i, o);
-            (*e)->DeleteLocalRef(e, o);
+            /* (after a failed allocation an OutOfMemoryError is pending: no more JNI calls that may not run with one, only frees) */
+            if (res && !(*e)->ExceptionCheck(e)) {
+                jbyteArray o = (*e)->NewByteArray(e, (jsize)olen[i]);
+                if (o) {
+                    (*e)->SetByteArrayRegion(e, o, 0, (jsize)olen[i], (const jbyte*)out[i]);
+                    (*e)->SetObjectArrayElement(e, res, i, o);
+                    (*e)->DeleteLocalRef(e, o);
+                }
+            }
             d4g_free(out[i]);
         }
     }
-    return res;
+    return (*e)->ExceptionCheck(e) ? NULL : res;
 }
 
 JNIEXPORT jint JNICALL JFN(init)(JNIEnv* e, jclass c, jint device) {
     (void)e; (void)c;
     return d4g_init(device);
+}
+
+/* int initDevices(int[] devices): context k = devices[k] (one JVM driving the GPUs of a node) */
+JNIEXPORT jint JNICALL JFN(initDevices)(JNIEnv* e, jclass c, jintArray devices) {
+    (void)c;
+    jsize n = (*e)->GetArrayLength(e, devices);
+    jint* d = (*e)->GetIntArrayElements(e, devices, NULL);
+    if (!d) return D4G_ERR_RUNTIME;
+    int rc = d4g_init_devices((int)n, (const int*)d);
+    (*e)->ReleaseIntArrayElements(e, devices, d, JNI_ABORT);
+    return rc;
+}
+JNIEXPORT jint JNICALL JFN(deviceCount)(JNIEnv* e, jclass c) {
+    (void)e; (void)c;
+    return d4g_device_count();
+}
+/* the calling Java thread's context from now on (a pool thread per GPU: CompressionUtil.java:111-117) */
+JNIEXPORT jint JNICALL JFN(setDevice)(JNIEnv* e, jclass c, jint context) {
+    (void)e; (void)c;
+    return d4g_set_device(context);
 }
 
 /* byte[][] optimiseStreams(byte[][] in, boolean mergeBlocks, long[] savedBits, int[] status): entry i of the result is
@@ -87,8 +119,30 @@ JNIEXPORT jobjectArray JNICALL JFN(optimiseStreams)(JNIEnv* e, jclass c, jobject
         if (d4g_optimise_streams((size_t)L.n, L.ptr, L.len, merge ? 1 : 0, out, olen, saved, status) != D4G_OK)
             for (jsize i = 0; i < L.n; i++) { status[i] = D4G_STREAM_UNCHANGED; saved[i] = 0; }   /* out[] is all NULL on failure */
         res = to_java(e, L.n, out, olen);
-        (*e)->SetLongArrayRegion(e, savedOut, 0, L.n, (const jlong*)saved);
-        (*e)->SetIntArrayRegion(e, statusOut, 0, L.n, (const jint*)status);
+        if (res && (*e)->GetArrayLength(e, savedOut) >= L.n) (*e)->SetLongArrayRegion(e, savedOut, 0, L.n, (const jlong*)saved);
+        if (res && (*e)->GetArrayLength(e, statusOut) >= L.n) (*e)->SetIntArrayRegion(e, statusOut, 0, L.n, (const jint*)status);
+        free(out); free(olen); free(saved); free(status);
+    }
+    unpin(e, &L);
+    return res;
+}
+
+/* the same over every initialised context: the list is partitioned by size, one device batch per context, outputs gathered
+ * in list order (DeflateFilesContainer.optimise, K/DeflateFilesContainer.java:18-43) */
+JNIEXPORT jobjectArray JNICALL JFN(optimiseStreamsSharded)(JNIEnv* e, jclass c, jobjectArray in, jboolean merge, jlongArray savedOut, jintArray statusOut) {
+    (void)c;
+    in_list L = {0};
+    jobjectArray res = NULL;
+    if (pin(e, in, &L) == 0) {
+        uint8_t** out = calloc((size_t)L.n + 1, sizeof *out);
+        size_t* olen = calloc((size_t)L.n + 1, sizeof *olen);
+        int64_t* saved = calloc((size_t)L.n + 1, sizeof *saved);
+        int32_t* status = calloc((size_t)L.n + 1, sizeof *status);
+        if (d4g_optimise_streams_sharded((size_t)L.n, L.ptr, L.len, merge ? 1 : 0, out, olen, saved, status) != D4G_OK)
+            for (jsize i = 0; i < L.n; i++) { status[i] = D4G_STREAM_UNCHANGED; saved[i] = 0; }
+        res = to_java(e, L.n, out, olen);
+        if (res && (*e)->GetArrayLength(e, savedOut) >= L.n) (*e)->SetLongArrayRegion(e, savedOut, 0, L.n, (const jlong*)saved);
+        if (res && (*e)->GetArrayLength(e, statusOut) >= L.n) (*e)->SetIntArrayRegion(e, statusOut, 0, L.n, (const jint*)status);
         free(out); free(olen); free(saved); free(status);
     }
     unpin(e, &L);

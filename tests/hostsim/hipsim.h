@@ -136,6 +136,8 @@ struct RtGlobals {
     int device = 0;
     bool ready = false;
 };
+#define RT_MAX_CTX 16
+inline int& rt_ctx() { static int c = 0; return c; }   // (the emulator has one device: every context is the same)
 inline RtGlobals& rt() {
     static RtGlobals g;
     return g;

@@ -100,3 +100,42 @@ def test_shutdown_and_reinit(L):
     rc, res = abi_calls.optimise_streams(L, [a], True)
     assert rc == 0 and res[0][2] == want
     assert L.d4g_init(0) == 0                          # idempotent on the same device
+
+
+def test_two_contexts_on_one_gpu_and_the_sharded_one_shot():
+    """One process, several devices (d4g_init_devices): two logical contexts on the one GPU of the box — own memory pool,
+    own programs, own streams each.  A batch created on context 1, batches on both contexts driven from two threads at
+    once, and d4g_optimise_streams_sharded over both give byte for byte what context 0 alone gives."""
+    import deft4j_amd as D
+    D.init(0)
+    D.init_devices([0, 0])
+    lib = D.load_library()
+    assert lib.d4g_device_count() == 2
+    streams = [synth.make_stream(n, s) for n, s in ((60000, 1), (250000, 2), (3000, 3), (180000, 4), (90000, 5))] + [b"\x07", synth.deflate9(b"")]
+
+    def snap(b):
+        res = []
+        for i in range(len(streams)):
+            r = b.result(i)
+            res.append((r["status"], b.output(i) if r["status"] == 0 else None, r["saved_bits"] if r["status"] == 0 else 0))
+        return res
+    ref = D.Batch(streams).run(True)
+    want = snap(ref)
+    ref.close()
+    assert any(w[0] == 0 for w in want)
+    b1 = D.Batch(streams, context=1).run(True)
+    assert snap(b1) == want
+    b1.close()
+    got = {}
+
+    def work(ctx):
+        b = D.Batch(streams, context=ctx).run(True)
+        got[ctx] = snap(b)
+        b.close()
+    ts = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert got[0] == want and got[1] == want
+    outs, saved, status = D.optimise_streams_sharded(streams, True)
+    for i, (st, o, sv) in enumerate(want):
+        assert status[i] == st and saved[i] == sv and outs[i] == o

@@ -343,3 +343,26 @@ def test_zopfli_change_point_pool_grows_instead_of_failing(sim, monkeypatch):
         assert out[1] == ZF.deflate(S, 2, split, 15, 8 << 20, ZF.LOG_PORTABLE)
     # unlimited splitting (blocksplittingmax 0): more split points than the old fixed buffer is no longer an error either
     assert D.zopfli_streams([data], 1, ZF.SPLIT_FIRST, 0, 8 << 20, lib=L)[0] == ZF.deflate(data, 1, ZF.SPLIT_FIRST, 0, 8 << 20, ZF.LOG_PORTABLE)
+
+
+def test_contexts_and_the_sharded_one_shot_in_the_emulator(sim):
+    """d4g_init_devices / d4g_batch_create_on / d4g_optimise_streams_sharded (one process driving several GPUs): two
+    contexts (the emulator has one device behind both): a batch created on context 1 and the sharded one-shot give what
+    the single-context calls give."""
+    D, L = sim
+    D.init_devices([0, 0], lib=L)
+    assert L.d4g_device_count() == 2
+    streams = [synth.make_stream(n, s) for n, s in ((900, 1), (2500, 2), (300, 3), (1800, 4))] + [b"\x07", synth.deflate9(b"")]
+    want = [O.optimise(a, True) for a in streams]
+    b = D.Batch(streams, lib=L, context=1).run(True)
+    for i, w in enumerate(want):
+        assert b.result(i)["status"] == w[0]
+        if w[0] == 0:
+            assert b.output(i) == w[1]
+    b.close()
+    outs, saved, status = D.optimise_streams_sharded(streams, True, lib=L)
+    for i, w in enumerate(want):
+        assert status[i] == w[0] and outs[i] == (w[1] if w[0] == 0 else None) and saved[i] == (w[2] if w[0] == 0 else 0)
+    assert D.Batch(streams[:1], lib=L, context=0).run(False).output(0) == O.optimise(streams[0], False)[1]
+    with pytest.raises(RuntimeError):
+        D.Batch(streams[:1], lib=L, context=7)
