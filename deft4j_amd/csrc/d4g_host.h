@@ -938,6 +938,7 @@ struct Batch {
             stats.kernel_launches++;
             i64 maxU = 0;
             for (size_t i = 0; i < n; i++) maxU = std::max(maxU, ps[i].nU);
+            if (maxU >= (1LL << 31)) throw std::runtime_error("a stream decodes to 2 GiB or more");
             int G = (int)std::min<i64>(2048, std::max<i64>(1, (maxU + 4095) / 4096));
             unsigned long long* dChanged = (unsigned long long*)rt_malloc(40 * 8);   // one counter per round, zeroed once
             rt_memset(dChanged, 0, 40 * 8);
@@ -946,14 +947,40 @@ struct Batch {
             static int stopPct = -1;   // D4G_JUMP_STOP_PCT: stop doubling once fewer than this share of the bytes still moves
             if (stopPct < 0) { const char* t = getenv("D4G_JUMP_STOP_PCT"); stopPct = t ? atoi(t) : 50; }
             const unsigned long long stopNum = std::max<unsigned long long>(1, (unsigned long long)((totalU * stopPct + 99) / 100));   // the resolve pass walks what is left of the chains
-            const int JB = 10;   // rounds per batch: launched back to back, counters read once
+            // the first rounds tile by tile, out of the XCDs' L2 (k_jump_tiles); D4G_JUMP_TILE_REPS=0: plain rounds only
+            static const int tileReps = env_int("D4G_JUMP_TILE_REPS", 6);
+            void* jumpTmp[2] = {nullptr, nullptr};
+            if (tileReps > 0) {
+                std::vector<D4GJumpTile> tl;
+                for (size_t i = 0; i < n; i++)
+                    for (i64 q = 0; q < ps[i].nU; q += D4G_JUMP_TILE) tl.push_back({(int32_t)i, 0, q});
+                if (!tl.empty()) {
+                    // consecutive tiles -> workgroup ids equal mod 8 (one XCD, one L2): region x of the tile list goes to ids x, x + 8, ...
+                    const size_t nt = tl.size(), per = (nt + 7) / 8;
+                    std::vector<D4GJumpTile> ord(nt);
+                    size_t w = 0;
+                    for (size_t j = 0; j < per; j++)
+                        for (size_t x = 0; x < 8; x++) {
+                            const size_t t = x * per + j;
+                            if (t < nt) ord[w++] = tl[t];
+                        }
+                    D4GJumpTile* dTl = (D4GJumpTile*)rt_malloc(nt * sizeof(D4GJumpTile));
+                    rt_h2d(dTl, ord.data(), nt * sizeof(D4GJumpTile));
+                    unsigned long long* dCh0 = (unsigned long long*)rt_malloc(16);
+                    rt_memset(dCh0, 0, 16);
+                    RT_LAUNCH(k_jump_tiles, nt, 256, dStreams, dTl, dSrc, tileReps, dCh0);
+                    stats.kernel_launches++;
+                    jumpTmp[0] = dTl; jumpTmp[1] = dCh0;   // (freed with the other parse buffers, after the next synchronisation)
+                }
+            }
+            const int JB = tileReps > 0 ? 4 : 10;   // rounds per batch: launched back to back, counters read once (after the tile rounds one or two are left)
             for (int base = 0; base < 40; base += JB) {
                 for (int round = base; round < base + JB; round++) {
                     RT_LAUNCH(k_jump_streams, n * (size_t)G, 256, dStreams, dSrc, dChanged + round, G,
                               round == 0 ? (const unsigned long long*)nullptr : dChanged + round - 1, stopNum);
                     stats.kernel_launches++;
                 }
-                unsigned long long ch[JB];
+                unsigned long long ch[10];
                 rt_d2h(ch, dChanged + base, JB * 8);
                 if (getenv("D4G_DEBUG_JUMP")) {
                     fprintf(stderr, "jump rounds %d..%d of %lld bytes, moved:", base, base + JB - 1, (long long)totalU);
@@ -973,7 +1000,7 @@ struct Batch {
             rt_d2h(bad.data(), dBad, n * 4);
             for (size_t i = 0; i < n; i++)
                 if (bad[i]) throw std::runtime_error("parse: back-reference before the start of stream (host check missed it)");
-            rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged);
+            rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged); rt_free(jumpTmp[0]); rt_free(jumpTmp[1]);
         }
         block_bins(LY.realBlocks, needSlots);
         e1.record();

@@ -855,6 +855,9 @@ __global__ void __launch_bounds__(D4G_PARSE_MAXTHREADS) k_emit_blocks(const D4GS
 // copies from; literals and stored bytes point at themselves.
 // ---------------------------------------------------------------------------------------
 struct D4GTokRange { int32_t stream; int32_t stored; long long tokStart, tokCount, uStart, uLen; };
+// An entry whose top bit is set is final: the position in its low 31 bits holds the byte itself (a literal, a stored byte).
+// Final entries are never looked up again — by the last rounds that is most of them.  (A stream decodes to less than 2 GiB.)
+#define D4G_SRC_FINAL 0x80000000u
 
 __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, const D4GTokRange* ranges, const uint2* tok,
                                                   uint8_t* U, uint32_t* src, int32_t* badDist, int G) {
@@ -865,7 +868,7 @@ __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, 
     long long stride = (long long)G * blockDim.x;
     long long t0 = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x;
     if (r.stored) {
-        for (long long k = t0; k < r.uLen; k += stride) s[r.uStart + k] = (uint32_t)(r.uStart + k);
+        for (long long k = t0; k < r.uLen; k += stride) s[r.uStart + k] = (uint32_t)(r.uStart + k) | D4G_SRC_FINAL;
         return;
     }
     for (long long t = t0; t < r.tokCount; t += stride) {
@@ -873,10 +876,10 @@ __global__ void __launch_bounds__(256) k_fill_src(const D4GStreamDesc* streams, 
         uint32_t a = tk.x, pos = tk.y;
         int dist = tok_dist(a), val = tok_val(a);
         if (dist == 0) {
-            if (val < 256) { u[pos] = (uint8_t)val; s[pos] = pos; }
+            if (val < 256) { u[pos] = (uint8_t)val; s[pos] = pos | D4G_SRC_FINAL; }
         } else if ((uint32_t)dist > pos) {
             badDist[r.stream] = 1;  // reference: readSlice walks off the first block (NullPointerException)
-            for (int k = 0; k < val; k++) s[pos + k] = pos + k;
+            for (int k = 0; k < val; k++) s[pos + k] = (pos + k) | D4G_SRC_FINAL;
         } else {
             for (int k = 0; k < val; k++) s[pos + k] = pos + k - dist;
         }
@@ -899,7 +902,8 @@ __global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* strea
     for (long long q4 = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q4 < n4; q4 += stride) {
         const uint32_t q = (uint32_t)(q4 << 2);
         uint4 a = *(const uint4*)(s + q);
-        uint32_t b0 = s[a.x], b1 = s[a.y], b2 = s[a.z], b3 = s[a.w];   // (an entry that points at itself reads itself)
+        uint32_t b0 = (a.x & D4G_SRC_FINAL) ? a.x : s[a.x], b1 = (a.y & D4G_SRC_FINAL) ? a.y : s[a.y];
+        uint32_t b2 = (a.z & D4G_SRC_FINAL) ? a.z : s[a.z], b3 = (a.w & D4G_SRC_FINAL) ? a.w : s[a.w];
         bool c0 = b0 != a.x, c1 = b1 != a.y, c2 = b2 != a.z, c3 = b3 != a.w;
         if (c0 | c1 | c2 | c3) {
             *(uint4*)(s + q) = make_uint4(b0, b1, b2, b3);
@@ -909,11 +913,54 @@ __global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* strea
     if (blockIdx.x % G == 0 && threadIdx.x < (sd.uLen & 3)) {   // the last one to three entries
         long long q = (n4 << 2) + threadIdx.x;
         uint32_t a = s[q];
-        uint32_t b = s[a];
+        uint32_t b = (a & D4G_SRC_FINAL) ? a : s[a];
         if (b != a) { s[q] = b; any++; }
     }
     // how many entries moved this round (the host stops doubling once few do; k_resolve_streams walks the rest);
     // one global atomic per workgroup
+    __shared__ unsigned wgMoved;
+    if (threadIdx.x == 0) wgMoved = 0;
+    __syncthreads();
+    int tot = wave_sum_i32(any);
+    if (tot && (threadIdx.x & 63) == 0) atomicAdd(&wgMoved, (unsigned)tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && wgMoved) atomicAdd((unsigned long long*)changed, (unsigned long long)wgMoved);
+}
+// The first doubling rounds, tile by tile.  A round's gathers reach 32 KiB * 2^round back: for the first few rounds that is the
+// tile itself and a handful of tiles before it.  One workgroup owns one 32 Ki-entry tile and runs `reps` rounds over it in a
+// row while its neighbours (same XCD: consecutive tiles get workgroup ids that are equal mod 8) do the same to theirs, so the
+// entries and their targets are served by that XCD's L2 after the first touch instead of crossing to HBM every round.  In place
+// and unsynchronised like k_jump_streams: any value read is a position further up the same copy chain.
+#define D4G_JUMP_TILE 32768
+struct D4GJumpTile { int32_t stream, pad; long long first; };
+__global__ void __launch_bounds__(256) k_jump_tiles(const D4GStreamDesc* streams, const D4GJumpTile* tiles, uint32_t* src, int reps,
+                                                    unsigned long long* changed) {
+    const D4GJumpTile t = tiles[blockIdx.x];
+    const D4GStreamDesc sd = streams[t.stream];
+    uint32_t* s = src + sd.uBase;
+    const long long q0 = t.first, q1 = q0 + D4G_JUMP_TILE < sd.uLen ? q0 + D4G_JUMP_TILE : sd.uLen;
+    const long long n4 = (q1 - q0) >> 2;
+    int any = 0;
+    for (int rep = 0; rep < reps; rep++) {
+        any = 0;
+        for (long long k = threadIdx.x; k < n4; k += blockDim.x) {
+            const long long q = q0 + (k << 2);
+            uint4 a = *(const uint4*)(s + q);
+            uint32_t b0 = (a.x & D4G_SRC_FINAL) ? a.x : s[a.x], b1 = (a.y & D4G_SRC_FINAL) ? a.y : s[a.y];
+            uint32_t b2 = (a.z & D4G_SRC_FINAL) ? a.z : s[a.z], b3 = (a.w & D4G_SRC_FINAL) ? a.w : s[a.w];
+            bool c0 = b0 != a.x, c1 = b1 != a.y, c2 = b2 != a.z, c3 = b3 != a.w;
+            if (c0 | c1 | c2 | c3) {
+                *(uint4*)(s + q) = make_uint4(b0, b1, b2, b3);
+                any += (int)c0 + (int)c1 + (int)c2 + (int)c3;
+            }
+        }
+        if ((long long)threadIdx.x < ((q1 - q0) & 3)) {   // the last one to three entries of the stream
+            const long long q = q0 + (n4 << 2) + threadIdx.x;
+            uint32_t a = s[q];
+            uint32_t b = (a & D4G_SRC_FINAL) ? a : s[a];
+            if (b != a) { s[q] = b; any++; }
+        }
+    }
     __shared__ unsigned wgMoved;
     if (threadIdx.x == 0) wgMoved = 0;
     __syncthreads();
@@ -929,10 +976,10 @@ __global__ void __launch_bounds__(256) k_resolve_streams(const D4GStreamDesc* st
     long long stride = (long long)G * blockDim.x;
     for (long long q = (long long)(blockIdx.x % G) * blockDim.x + threadIdx.x; q < sd.uLen; q += stride) {
         uint32_t a = s[q];
-        if (a != (uint32_t)q) {
-            // (pointer doubling stops early: follow what is left of the chain — every hop lands on an ancestor)
-            for (uint32_t b = s[a]; b != a; b = s[a]) a = b;
-            u[q] = u[a];
+        if (a != ((uint32_t)q | D4G_SRC_FINAL)) {
+            // (pointer doubling stops early: follow what is left of the chain — every hop lands further up it)
+            while (!(a & D4G_SRC_FINAL)) a = s[a];
+            u[q] = u[a & ~D4G_SRC_FINAL];
         }
     }
 }
