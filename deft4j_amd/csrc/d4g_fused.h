@@ -79,7 +79,7 @@ struct D4FParams {
     const D4GOp* ops[2];    // [0] program of a DYNAMIC block, [1] of a FIXED block
     int32_t nOps[2];
     int32_t maxRounds;      // optimiseBlock rounds to run while the block keeps improving (1 for a merge attempt)
-    int32_t pad;
+    int32_t regWords;       // blocks of up to this many mask words take the register forms of the mask tasks (64 * D4F_NWR; tests: 0)
     D4GRoundResult* results;   // [nActive][D4F_MAXROUNDS]
     int32_t* roundInfo;        // [nActive]: rounds completed | D4F_INFO_*
     long long* stats;          // optional [32] counters
@@ -213,7 +213,7 @@ struct D4FLds {
     D4GBlock b;
     D4FGlob G;
     const D4GOp* ops;
-    int32_t nOps, curType, rounds, info, improved, pad1;
+    int32_t nOps, curType, rounds, info, improved, regWords;
     long long curSize;
 };
 
@@ -768,6 +768,22 @@ D4G_DEV void d4f_wave_for_bits(const uint64_t (&d)[D4F_NWR], const uint4* rf, ui
         d4g_wave_sync();
     }
 }
+// The same for a selection of any length (sel(w) = selection word w, read by the lane that owns it): 64 * D4F_NWR words a pass.
+template <typename Sel, typename Fn>
+D4G_DEV void d4f_wave_for_words(int nWords, int nRef, const uint4* rf, uint32_t* queue, Sel sel, Fn fn) {
+    const int lane = threadIdx.x & 63;
+    for (int w0 = 0; w0 < nWords; w0 += 64 * D4F_NWR) {
+        uint64_t d[D4F_NWR];
+#pragma unroll
+        for (int j = 0; j < D4F_NWR; j++) {
+            const int w = w0 + lane + 64 * j;
+            uint64_t v = w < nWords ? sel(w) : 0ull;
+            if (w == nWords - 1 && (nRef & 63)) v &= (1ull << (nRef & 63)) - 1;
+            d[j] = v;
+        }
+        d4f_wave_for_bits(d, rf + (size_t)w0 * 64, queue, fn);
+    }
+}
 // the wave's code tables from the code's lengths, words requested by the caller beforehand: w0 = word `lane` of lens, w1 = word 64 + lane (lanes < 16)
 D4G_DEV void d4f_wave_code_from_words(D4FWaveScr& W, uint32_t w0, uint32_t w1) {
     const int lane = threadIdx.x & 63;
@@ -805,7 +821,7 @@ D4F_TASK void d4f_apply_task(int idx) {
     const uint4* rf = c.refs + b.refStart;
     const uint8_t* Ub = c.U + b.uBase;
     const uint32_t* Uw = (const uint32_t*)Ub;
-    if (nWords <= 64 * D4F_NWR) {
+    if (nWords <= F.regWords) {
         // register form: everything the task reads up front goes out in one round trip (mask and E words, the histogram,
         // the code's lengths), the selected records in a second one
         uint64_t ew[D4F_NWR], mw[D4F_NWR], d[D4F_NWR];
@@ -893,8 +909,8 @@ D4F_TASK void d4f_apply_task(int idx) {
     }
     d4f_wave_load_code(W, G.code[code]);
     int savedLane = 0, bad = 0;
-    wave_for_selected(0, 1, nWords, nRef, rf, W.queue, [&](int w) { return E[w] & ~M[w]; },
-                      [&](int, uint4 rv) {
+    d4f_wave_for_words(nWords, nRef, rf, W.queue, [&](int w) { return E[w] & ~M[w]; },
+                      [&](const uint4& rv) {
                           const uint32_t a = rv.x;
                           const int cost = W.cl[ref_lsym(a) - 257] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
                           const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
@@ -973,7 +989,7 @@ D4F_TASK void d4f_least_task(int idx) {
     const uint32_t* Uw = (const uint32_t*)Ub;
     const uint32_t* stat = c.binStat + b.binStat;
     const uint64_t* bmask = c.binMask + b.binMask;
-    if (nWords <= 64 * D4F_NWR) {
+    if (nWords <= F.regWords) {
         // register form (see d4f_apply_task).  Length symbols whose records are ALL expanded already (an earlier pruning
         // step took them) have no unexpanded record, so they are never chosen whatever their sums: their records — often
         // thousands — are left out of the walk.
@@ -1125,8 +1141,8 @@ D4F_TASK void d4f_least_task(int idx) {
     }
     d4g_wave_sync();
     if (viaExpanded) {
-        wave_for_selected(0, 1, nWords, nRef, rf, W.queue, [&](int w) { return M[w]; },
-                          [&](int, uint4 rv) {
+        d4f_wave_for_words(nWords, nRef, rf, W.queue, [&](int w) { return M[w]; },
+                      [&](const uint4& rv) {
                               const uint32_t a = rv.x;
                               const int bin = ref_lsym(a) - 257;
                               const int cost = W.cl[bin] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
@@ -1136,8 +1152,8 @@ D4F_TASK void d4f_least_task(int idx) {
                               if (total >= D4G_NO_CODE) atomicSub(&W.binZ[bin], total >> 14);
                           });
     } else {
-        wave_for_selected(0, 1, nWords, nRef, rf, W.queue, [&](int w) { return ~M[w]; },
-                          [&](int, uint4 rv) {
+        d4f_wave_for_words(nWords, nRef, rf, W.queue, [&](int w) { return ~M[w]; },
+                      [&](const uint4& rv) {
                               const uint32_t a = rv.x;
                               const int bin = ref_lsym(a) - 257;
                               const int cost = W.cl[bin] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
@@ -1174,8 +1190,8 @@ D4F_TASK void d4f_least_task(int idx) {
     for (int i = lane; i < D4G_HIST; i += 64) { W.hist[i] = G.hist[(size_t)m * D4G_HIST + i]; W.delta[i] = 0; }
     d4g_wave_sync();
     // what the already expanded records of the bin contributed to the static row (they were moved earlier)
-    wave_for_selected(0, 1, nWords, nRef, rf, W.queue, [&](int w) { return M[w] & bm[w]; },
-                      [&](int, uint4 rv) {
+    d4f_wave_for_words(nWords, nRef, rf, W.queue, [&](int w) { return M[w] & bm[w]; },
+                      [&](const uint4& rv) {
                           const uint32_t a = rv.x;
                           atomicAdd(&W.delta[D4G_BIN_DIST + ref_dsym(a)], 1);
                           atomicAdd(&W.delta[D4G_BIN_COUNT], 1);
@@ -1832,6 +1848,7 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
     if (threadIdx.x == 0) {
         const int blk = cArg.active[blockIdx.x];
         F.nCode = 2;
+        F.regWords = P.regWords < 64 * D4F_NWR ? P.regWords : 64 * D4F_NWR;
         F.c = cArg;
         F.b = cArg.blocks[blk];
         F.G = d4f_glob(cArg, blk);

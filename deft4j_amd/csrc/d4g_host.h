@@ -73,9 +73,14 @@ static inline bool exec_fused() {
     const char* t = getenv("D4G_EXEC");
     return !t || !strcmp(t, "fused");
 }
-static inline long long fused_max_refs() {   // blocks with more back-references than this go to the level / persistent executors
+// Blocks with more back-references than this go to the level / persistent executors.  The fused executor is one workgroup
+// per block: unbeatable while there are blocks enough to fill the device, but a lone long block (the merge chain of one
+// big stream: 3.8 ms per round at 100 k back-references with the persistent executor's many workgroups, 7.5 ms fused) is
+// better served by op-level parallelism.  Measured on config 2 with merge on / 64 x 1 MiB with merge on.
+static inline long long fused_max_refs(size_t nActive) {
     const char* t = getenv("D4G_FUSED_MAX_REFS");
-    return t ? atoll(t) : (1LL << 17);
+    if (t) return atoll(t);
+    return nActive >= 32 ? (1LL << 17) : (1LL << 14);
 }
 static inline int exec_persistent(int nActive = 0) {
     // read per call (not cached): the parity tests switch executors inside one process
@@ -1036,7 +1041,7 @@ struct Batch {
         std::vector<int> small, big;
         std::vector<size_t> smallPos, bigPos;
         for (size_t i = 0; i < act.size(); i++) {
-            if (hBlocks[act[i]].refCount <= fused_max_refs()) { small.push_back(act[i]); smallPos.push_back(i); }
+            if (hBlocks[act[i]].refCount <= fused_max_refs(act.size())) { small.push_back(act[i]); smallPos.push_back(i); }
             else { big.push_back(act[i]); bigPos.push_back(i); }
         }
         if (!small.empty()) {
@@ -1076,6 +1081,7 @@ struct Batch {
             memset(&P, 0, sizeof(P));
             P.ops[0] = E.progDyn.dOps; P.ops[1] = E.progFixed.dOps;
             P.nOps[0] = (int)E.progDyn.ops.size(); P.nOps[1] = (int)E.progFixed.ops.size();
+            P.regWords = env_int("D4G_FUSED_REG_WORDS", 64 * D4F_NWR);
             P.results = dRes;
             P.roundInfo = dInfo;
             P.stats = getenv("D4G_FUSED_STATS") ? E.dOpStats : nullptr;
@@ -1334,7 +1340,7 @@ struct Batch {
             std::vector<int> fa, rest;
             std::vector<std::pair<int, int>> fo, ro;
             for (size_t i = 0; i < act.size(); i++) {
-                if (hBlocks[act[i]].refCount <= fused_max_refs()) { fa.push_back(act[i]); fo.push_back(owner[i]); }
+                if (hBlocks[act[i]].refCount <= fused_max_refs(act.size())) { fa.push_back(act[i]); fo.push_back(owner[i]); }
                 else { rest.push_back(act[i]); ro.push_back(owner[i]); }
             }
             if (!fa.empty()) {

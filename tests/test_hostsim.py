@@ -366,3 +366,18 @@ def test_contexts_and_the_sharded_one_shot_in_the_emulator(sim):
     assert D.Batch(streams[:1], lib=L, context=0).run(False).output(0) == O.optimise(streams[0], False)[1]
     with pytest.raises(RuntimeError):
         D.Batch(streams[:1], lib=L, context=7)
+
+
+def test_fused_executor_mask_tasks_in_their_any_length_form(sim, monkeypatch):
+    """The fused executor's mask tasks have a register form (blocks of up to 16384 back-references) and a chunked form for
+    longer (merged) blocks: D4G_FUSED_REG_WORDS=0 sends every block through the chunked form."""
+    monkeypatch.setenv("D4G_FUSED_REG_WORDS", "0")
+    D, L = sim
+    ins = [synth.make_stream(9000, 21), synth.make_stream(2500, 22), synth.deflate9(synth.pngidat(6000, 3, 64))]
+    for merge in (False, True):
+        b = D.Batch(ins, lib=L).run(merge)
+        for i, a in enumerate(ins):
+            rc, want, saved, _, _ = O.optimise(a, merge)
+            assert b.result(i)["status"] == rc and b.output(i) == want and b.result(i)["saved_bits"] == saved, (i, merge)
+        assert b.stats()["rounds_fused"] > 0
+        b.close()
