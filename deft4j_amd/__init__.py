@@ -37,7 +37,7 @@ class d4g_stats(ctypes.Structure):
                 ("recompress_outputs", ctypes.c_int64), ("recompress_outputs_pruned", ctypes.c_int64),
                 ("ms_zopfli_table", ctypes.c_double), ("ms_zopfli_split", ctypes.c_double), ("ms_zopfli_squeeze", ctypes.c_double),
                 ("ms_zopfli_emit", ctypes.c_double), ("zopfli_blocks", ctypes.c_int64), ("zopfli_position_iterations", ctypes.c_int64),
-                ("rounds_fused", ctypes.c_int64), ("fused_fallbacks", ctypes.c_int64), ("persist_fallbacks", ctypes.c_int64)]
+                ("rounds_fused", ctypes.c_int64), ("fused_fallbacks", ctypes.c_int64), ("persist_fallbacks", ctypes.c_int64), ("rounds_cluster", ctypes.c_int64)]
 
 
 class d4g_encoder_spec(ctypes.Structure):

@@ -84,6 +84,44 @@ struct D4FParams {
     int32_t* roundInfo;        // [nActive]: rounds completed | D4F_INFO_*
     long long* stats;          // optional [32] counters
 };
+// ---- cluster mode: many workgroups on ONE long block (the merge chain of a big stream) ----
+// Workgroup 0 runs the search exactly as k_search_fused does; what scales with the block's length — the sweeps over the
+// records, the mask updates, the record walks of the least-expensive pruning — it posts as *commands* that every workgroup
+// of the launch, itself included, works off in items of a few thousand records.  The control workgroup never depends on a
+// helper being resident: it takes items itself until none is left and then waits only for items already taken.
+// Hand-off discipline (per-XCD L2s are not coherent): every command uses a FRESH slot of the arena (no workgroup has ever
+// read those lines); parameters are written through (sc1), accumulators are device-scope atomics; bulk results (E-set and
+// mask words) are written once to lines nobody has read, then released; readers acquire before their first read.
+#define D4F_CL_MAXT 48        // tasks per command
+#define D4F_CL_SLOTS 96       // command slots of a launch (more commands than that: the control workgroup works alone)
+#define D4F_CL_CHUNK (64 * D4F_NWR)   // mask words per item of the mask commands
+#define D4F_CL_SWEEP_WORDS 16 // mask words per item of a sweep
+enum { D4F_CMD_SWEEP = 1, D4F_CMD_APPLY = 2, D4F_CMD_LEAST_WALK = 3, D4F_CMD_LEAST_EXPAND = 4 };
+struct D4FClTask {
+    int32_t m, code, prune, leaf, mNew, mode, rem, via;
+    uint32_t full;
+    int32_t pad0[3];
+    int32_t cnt, saved;                 // accumulators from here on (atomics)
+    unsigned long long h1, h2;
+    int32_t bin[3][32];                 // size, freq, bytes without a code — per length symbol
+    int32_t delta[D4G_HIST];
+    int32_t pad1[14];
+};
+static_assert(sizeof(D4FClTask) % 128 == 0, "tasks on cache lines of their own");
+struct D4FClCmd {
+    int32_t cmd, nItems, nTasks, nk, nChunks, pad0[3];
+    int32_t codes[D4F_SWEEP_K];
+    int32_t next, done, pad1[14];       // atomics (a line of their own)
+    uint32_t neq[D4F_SWEEP_K];
+    int32_t pad2[24];
+    D4FClTask task[D4F_CL_MAXT];
+};
+struct D4FClArena {
+    int32_t epoch;                      // commands posted (atomic); -1: the launch is over
+    int32_t pad[31];
+    D4FClCmd slot[D4F_CL_SLOTS];
+};
+
 #define D4F_INFO_FALLBACK 0x10000   // the round after the completed ones did not fit the tables: run it with the level executor
 #define D4F_INFO_MORE 0x20000       // still improving when maxRounds was reached
 
@@ -214,6 +252,9 @@ struct D4FLds {
     D4FGlob G;
     const D4GOp* ops;
     int32_t nOps, curType, rounds, info, improved, regWords;
+    struct D4FClArena* cl;    // cluster mode (k_search_cluster): the command area shared with the helper workgroups, else null
+    int32_t clEpoch, clDoneWg; // commands posted so far / items this workgroup finished in the command in hand
+    int32_t which, pad3;       // the block's index in the launch's active list
     long long curSize;
 };
 
@@ -568,75 +609,92 @@ D4F_TASK bool d4f_advance_op(const D4GOp op, int opId, long long* bestKeyP) {
 // Record r is in E1(code) when all its bytes have codes and their bits sum to no more than the back-reference's own
 // bits, in E0 when they sum to less (replaceWithLiteralsIfSmaller's `prune` / plain comparison, :222-296).
 // ---------------------------------------------------------------------------------------
-D4F_TASK void d4f_sweep() {
+// the sweep's LDS tables for `nk` codes (all threads; ends with a barrier)
+__device__ __forceinline__ void d4f_sweep_tables(const int32_t* codes, int nk) {
     D4FLds& F = d4fLds;
     D4F_CTX;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int nq = F.qn[D4F_Q_SWEEP] < D4F_QCAP_SWEEP ? F.qn[D4F_Q_SWEEP] : D4F_QCAP_SWEEP;
+    D4FSweepScr& S = F.scr.sweep;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk * 256; i += blockDim.x) {
+        const int k = i >> 8, v = i & 255;
+        const int l = G.code[codes[k]].lens[v];
+        S.lc[k][v] = (uint16_t)(l ? l : D4G_NO_CODE);
+    }
+    for (int i = threadIdx.x; i < nk * 64; i += blockDim.x) {
+        const int k = i >> 6, j = i & 63;
+        const uint8_t* ln = G.code[codes[k]].lens;
+        S.cl[k][j] = j < 29 ? ln[257 + j] : (j >= 32 && j < 62) ? ln[D4G_NLIT + j - 32] : 0;
+    }
+    if (threadIdx.x < D4F_SWEEP_K) S.neq[threadIdx.x] = 0;
+    __syncthreads();
+}
+// one wave: mask words wLo, wLo + step, ... below wHi of the E-sets of the table's codes (S.neq[k] is set where E0 != E1)
+__device__ __forceinline__ void d4f_sweep_words(const int32_t* codes, int nk, int wLo, int wHi, int step) {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    const int lane = threadIdx.x & 63;
     D4FSweepScr& S = F.scr.sweep;
     const uint4* rf = c.refs + b.refStart;
     const uint32_t* Uw = (const uint32_t*)(c.U + b.uBase);
-    const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
-    for (int base = 0; base < nq; base += D4F_SWEEP_K) {
-        const int nk = nq - base < D4F_SWEEP_K ? nq - base : D4F_SWEEP_K;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nk * 256; i += blockDim.x) {
-            const int k = i >> 8, v = i & 255;
-            const int l = G.code[F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + k]].lens[v];
-            S.lc[k][v] = (uint16_t)(l ? l : D4G_NO_CODE);
-        }
-        for (int i = threadIdx.x; i < nk * 64; i += blockDim.x) {
-            const int k = i >> 6, j = i & 63;
-            const uint8_t* ln = G.code[F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + k]].lens;
-            S.cl[k][j] = j < 29 ? ln[257 + j] : (j >= 32 && j < 62) ? ln[D4G_NLIT + j - 32] : 0;
-        }
-        if (threadIdx.x < D4F_SWEEP_K) S.neq[threadIdx.x] = 0;
-        __syncthreads();
-        uint4 nrec = make_uint4(0u, 0u, 0u, 0u);
-        if (wave < nWords) { int r = wave * 64 + lane; if (r < nRef) nrec = rf[r]; }
-        for (int w = wave; w < nWords; w += nw) {
-            const uint4 rec = nrec;
-            nrec = make_uint4(0u, 0u, 0u, 0u);
-            if (w + nw < nWords) { int r = (w + nw) * 64 + lane; if (r < nRef) nrec = rf[r]; }
-            const uint32_t a = rec.x;
-            const int len = ref_len(a);
-            const int ls = ref_lsym(a) - 257, ds = ref_dsym(a), eb = ref_ebits(a);
-            for (int k = 0; k < nk; k++) {
-                const uint16_t* lc = S.lc[k];
-                int e0 = 0, e1 = 0;
-                if (len > 0) {
-                    const int cost = S.cl[k][ls] + S.cl[k][32 + ds] + eb;
-                    uint32_t x = rec.z;
-                    int t = lc[x & 255u] + lc[(x >> 8) & 255u] + lc[(x >> 16) & 255u] + (len > 3 ? lc[x >> 24] : 0);
-                    if (len > 4 && t <= cost) {
-                        x = rec.w;
-                        const int n = len - 4;
-                        t += lc[x & 255u] + (n > 1 ? lc[(x >> 8) & 255u] : 0) + (n > 2 ? lc[(x >> 16) & 255u] : 0) + (n > 3 ? lc[x >> 24] : 0);
-                        if (len > 8 && t <= cost) {   // the rare long walk: the rest comes from U, four bytes per step
-                            D4GLitWalk lw;
-                            lw_start(lw, Uw, rec.y + 8, len - 8);
-                            lw.total = t;
-                            while (lw.rem > 0 && lw.total <= cost) lw_step(lw, Uw, lc);
-                            t = lw.total;
-                        }
+    const int nRef = (int)b.refCount;
+    uint4 nrec = make_uint4(0u, 0u, 0u, 0u);
+    if (wLo < wHi) { int r = wLo * 64 + lane; if (r < nRef) nrec = rf[r]; }
+    for (int w = wLo; w < wHi; w += step) {
+        const uint4 rec = nrec;
+        nrec = make_uint4(0u, 0u, 0u, 0u);
+        if (w + step < wHi) { int r = (w + step) * 64 + lane; if (r < nRef) nrec = rf[r]; }
+        const uint32_t a = rec.x;
+        const int len = ref_len(a);
+        const int ls = ref_lsym(a) - 257, ds = ref_dsym(a), eb = ref_ebits(a);
+        for (int k = 0; k < nk; k++) {
+            const uint16_t* lc = S.lc[k];
+            int e0 = 0, e1 = 0;
+            if (len > 0) {
+                const int cost = S.cl[k][ls] + S.cl[k][32 + ds] + eb;
+                uint32_t x = rec.z;
+                int t = lc[x & 255u] + lc[(x >> 8) & 255u] + lc[(x >> 16) & 255u] + (len > 3 ? lc[x >> 24] : 0);
+                if (len > 4 && t <= cost) {
+                    x = rec.w;
+                    const int n = len - 4;
+                    t += lc[x & 255u] + (n > 1 ? lc[(x >> 8) & 255u] : 0) + (n > 2 ? lc[(x >> 16) & 255u] : 0) + (n > 3 ? lc[x >> 24] : 0);
+                    if (len > 8 && t <= cost) {   // the rare long walk: the rest comes from U, four bytes per step
+                        D4GLitWalk lw;
+                        lw_start(lw, Uw, rec.y + 8, len - 8);
+                        lw.total = t;
+                        while (lw.rem > 0 && lw.total <= cost) lw_step(lw, Uw, lc);
+                        t = lw.total;
                     }
-                    e1 = t <= cost;
-                    e0 = t < cost;
                 }
-                const unsigned long long b1 = __ballot(e1), b0 = __ballot(e0);
-                if (lane == 0) {
-                    const int code = F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + k];
-                    d4f_eset(c, b, code, 0)[w] = b0;
-                    d4f_eset(c, b, code, 1)[w] = b1;
-                    if (b0 != b1) S.neq[k] = 1;
-                }
+                e1 = t <= cost;
+                e0 = t < cost;
+            }
+            const unsigned long long b1 = __ballot(e1), b0 = __ballot(e0);
+            if (lane == 0) {
+                d4f_eset(c, b, codes[k], 0)[w] = b0;
+                d4f_eset(c, b, codes[k], 1)[w] = b1;
+                if (b0 != b1) S.neq[k] = 1;
             }
         }
+    }
+}
+D4F_TASK void d4f_sweep() {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nq = F.qn[D4F_Q_SWEEP] < D4F_QCAP_SWEEP ? F.qn[D4F_Q_SWEEP] : D4F_QCAP_SWEEP;
+    D4FSweepScr& S = F.scr.sweep;
+    const int nWords = (int)b.maskWords;
+    for (int base = 0; base < nq; base += D4F_SWEEP_K) {
+        const int nk = nq - base < D4F_SWEEP_K ? nq - base : D4F_SWEEP_K;
+        int32_t* codes = &F.misc[16];
+        __syncthreads();
+        if ((int)threadIdx.x < nk) codes[threadIdx.x] = F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + threadIdx.x];
+        d4f_sweep_tables(codes, nk);
+        d4f_sweep_words(codes, nk, wave, nWords, nw);
         __syncthreads();
         if ((int)threadIdx.x < nk) {
-            const int code = F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + threadIdx.x];
-            F.eEq[code] = S.neq[threadIdx.x] ? 0 : 1;
-            F.eState[code] = 2;
+            F.eEq[codes[threadIdx.x]] = S.neq[threadIdx.x] ? 0 : 1;
+            F.eState[codes[threadIdx.x]] = 2;
         }
     }
     __syncthreads();
@@ -1610,6 +1668,375 @@ D4F_TASK void d4f_hs_task(int slotIdx, int code) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Cluster mode (see the notes at D4FClArena): the worker every workgroup runs on a posted command, and the control
+// workgroup's side of the three kinds of step that scale with the block's length.
+// ---------------------------------------------------------------------------------------
+#ifdef D4G_HOSTSIM
+D4G_DEV int d4f_atomic_ld(const int32_t* p) { return *p; }
+D4G_DEV void d4f_atomic_st(int32_t* p, int v) { *p = v; }
+#else
+D4G_DEV int d4f_atomic_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+D4G_DEV void d4f_atomic_st(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+D4G_DEV D4FClCmd& d4f_cl_cmd() { return d4fLds.cl->slot[(d4fLds.clEpoch - 1) % D4F_CL_SLOTS]; }
+
+// Work on the command in hand until no item is left.  All threads of a workgroup call; any workgroup of the launch may.
+D4F_TASK void d4f_cl_work() {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    D4FClCmd& C = d4f_cl_cmd();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cmd = C.cmd, nItems = C.nItems, nChunks = C.nChunks, nk = C.nk;
+    const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
+    if (threadIdx.x == 0) F.clDoneWg = 0;
+    if (cmd == D4F_CMD_SWEEP) d4f_sweep_tables(C.codes, nk);
+    else __syncthreads();
+    D4FWaveScr& W = F.scr.wave[wave & 7];
+    uint32_t* Wd = (uint32_t*)W.delta;
+    const uint4* rf = c.refs + b.refStart;
+    const uint8_t* Ub = c.U + b.uBase;
+    const uint32_t* Uw = (const uint32_t*)Ub;
+    const uint64_t* bmask = c.binMask + b.binMask;
+    int myDone = 0, cur = -1;
+    // the task in hand (wave-uniform) and this wave's share of its sums
+    int tm = 0, tcode = 0, tprune = 0, tleaf = 0, tnew = 0, trem = -1, tvia = 0;
+    uint32_t tfull = 0;
+    int cntLane = 0, savedLane = 0, badLane = 0;
+    unsigned long long h1Lane = 0, h2Lane = 0;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        D4FClTask& T = C.task[cur];
+        const int cnt = wave_sum_i32(cntLane), saved = wave_sum_i32(savedLane);
+        const unsigned long long h1 = (unsigned long long)wave_sum_i64((long long)h1Lane), h2 = (unsigned long long)wave_sum_i64((long long)h2Lane);
+        if (lane == 0) {
+            if (cnt) atomicAdd(&T.cnt, cnt);
+            if (saved) atomicAdd(&T.saved, saved);
+            if (h1) atomicAdd(&T.h1, h1);
+            if (h2) atomicAdd(&T.h2, h2);
+        }
+        d4g_wave_sync();
+        if (cmd == D4F_CMD_LEAST_WALK) {
+            if (lane < D4G_NBINS) {
+                if (W.binSize[lane]) atomicAdd(&T.bin[0][lane], W.binSize[lane]);
+                if (W.binFreq[lane]) atomicAdd(&T.bin[1][lane], W.binFreq[lane]);
+                if (W.binZ[lane]) atomicAdd(&T.bin[2][lane], W.binZ[lane]);
+            }
+        } else {
+            for (int i = lane; i < D4G_HIST; i += 64) { const int v = (int)Wd[i]; if (v) atomicAdd(&T.delta[i], v); }
+        }
+        if (__ballot(badLane) && lane == 0) atomicAdd(c.errors, 1);
+        d4g_wave_sync();
+    };
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(&C.next, 1);
+        item = __shfl(item, 0);
+        if (item >= nItems) break;
+        myDone++;
+        if (cmd == D4F_CMD_SWEEP) {
+            const int w0 = item * D4F_CL_SWEEP_WORDS;
+            d4f_sweep_words(C.codes, nk, w0, w0 + D4F_CL_SWEEP_WORDS < nWords ? w0 + D4F_CL_SWEEP_WORDS : nWords, 1);
+            continue;
+        }
+        const int t = item / nChunks, w0 = (item - t * nChunks) * D4F_CL_CHUNK;
+        if (t != cur) {
+            flush();
+            cur = t;
+            const D4FClTask& T = C.task[t];
+            tm = T.m; tcode = T.code; tprune = T.prune; tleaf = T.leaf; tnew = T.mNew; trem = T.rem; tvia = T.via; tfull = T.full;
+            cntLane = 0; savedLane = 0; badLane = 0; h1Lane = 0; h2Lane = 0;
+            for (int i = lane; i < D4G_HIST; i += 64) Wd[i] = 0;
+            if (lane < 32) { W.binSize[lane] = 0; W.binFreq[lane] = 0; W.binZ[lane] = 0; }
+            if (cmd != D4F_CMD_LEAST_EXPAND) {
+                const uint32_t* lw = (const uint32_t*)G.code[tcode].lens;
+                d4f_wave_code_from_words(W, lw[lane], lane < 16 ? lw[64 + lane] : 0u);
+            }
+            d4g_wave_sync();
+        }
+        const uint64_t* M = d4f_mask(c, b, tm);
+        uint64_t mw[D4F_NWR], xw[D4F_NWR], d[D4F_NWR];
+        if (cmd == D4F_CMD_APPLY) {
+            const uint64_t* E = d4f_eset(c, b, tcode, tprune);
+            uint64_t* O = (!tleaf && tnew) ? d4f_mask(c, b, tnew) : nullptr;
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) {
+                const int w = w0 + lane + 64 * j;
+                mw[j] = w < nWords ? M[w] : 0ull;
+                xw[j] = w < nWords ? E[w] : 0ull;
+                d[j] = xw[j] & ~mw[j];
+                cntLane += __popcll(d[j]);
+                if (O && w < nWords) {
+                    const uint64_t o = mw[j], n = o | xw[j];
+                    O[w] = n;
+                    if (n != o) { h1Lane += d4f_mix1(w, n) - d4f_mix1(w, o); h2Lane += d4f_mix2(w, n) - d4f_mix2(w, o); }
+                }
+            }
+            d4f_wave_for_bits(d, rf + (size_t)w0 * 64, W.queue, [&](const uint4& rv) {
+                const uint32_t a = rv.x;
+                const int cost = W.cl[ref_lsym(a) - 257] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
+                const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
+                const int gain = cost - total;
+                if (gain < (tprune ? 0 : 1)) badLane = 1;
+                savedLane += gain;
+                if (!tleaf) d4f_rec_to_hist(Wd, Ub, rv);
+            });
+        } else if (cmd == D4F_CMD_LEAST_WALK) {
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) {
+                const int w = w0 + lane + 64 * j;
+                mw[j] = w < nWords ? M[w] : 0ull;
+                xw[j] = 0ull;
+            }
+            if (tvia)
+                for (uint32_t fb = tfull; fb; fb &= fb - 1) {
+                    const uint64_t* fm = bmask + (long long)(__ffs((int)fb) - 1) * nWords;
+#pragma unroll
+                    for (int j = 0; j < D4F_NWR; j++) { const int w = w0 + lane + 64 * j; if (w < nWords) xw[j] |= fm[w]; }
+                }
+#pragma unroll
+            for (int j = 0; j < D4F_NWR; j++) {
+                const int w = w0 + lane + 64 * j;
+                uint64_t valid = w < nWords ? ~0ull : 0ull;
+                if (w == nWords - 1 && (nRef & 63)) valid = (1ull << (nRef & 63)) - 1;
+                d[j] = tvia ? (mw[j] & ~xw[j]) : (~mw[j] & valid);
+            }
+            const int sgn = tvia ? -1 : 1;
+            d4f_wave_for_bits(d, rf + (size_t)w0 * 64, W.queue, [&](const uint4& rv) {
+                const uint32_t a = rv.x;
+                const int bin = ref_lsym(a) - 257;
+                const int cost = W.cl[bin] + W.cl[32 + ref_dsym(a)] + ref_ebits(a);
+                const int total = d4f_rec_lit_total(Uw, W.lc, rv, ref_len(a));
+                atomicAdd(&W.binSize[bin], sgn * ((total & (D4G_NO_CODE - 1)) - cost));
+                atomicAdd(&W.binFreq[bin], sgn);
+                if (total >= D4G_NO_CODE) atomicAdd(&W.binZ[bin], sgn * (total >> 14));
+            });
+        } else if (cmd == D4F_CMD_LEAST_EXPAND) {
+            if (trem >= 0 && tnew) {
+                const uint64_t* bm = bmask + (long long)trem * nWords;
+                uint64_t* O = d4f_mask(c, b, tnew);
+#pragma unroll
+                for (int j = 0; j < D4F_NWR; j++) {
+                    const int w = w0 + lane + 64 * j;
+                    mw[j] = w < nWords ? M[w] : 0ull;
+                    xw[j] = w < nWords ? bm[w] : 0ull;
+                    d[j] = mw[j] & xw[j];
+                    if (w < nWords) {
+                        const uint64_t o = mw[j], n = o | xw[j];
+                        O[w] = n;
+                        cntLane += __popcll(n & ~o);
+                        if (n != o) { h1Lane += d4f_mix1(w, n) - d4f_mix1(w, o); h2Lane += d4f_mix2(w, n) - d4f_mix2(w, o); }
+                    }
+                }
+                // what the already expanded records of the bin contributed to the static row (they were moved earlier)
+                d4f_wave_for_bits(d, rf + (size_t)w0 * 64, W.queue, [&](const uint4& rv) {
+                    const uint32_t a = rv.x;
+                    atomicAdd(&Wd[D4G_BIN_DIST + ref_dsym(a)], 1u);
+                    atomicAdd(&Wd[D4G_BIN_COUNT], 1u);
+                    for_bytes(Ub + rv.y, ref_len(a), [&](int by) { atomicAdd(&Wd[by], 1u); return true; });
+                });
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    if (cmd == D4F_CMD_SWEEP && (int)threadIdx.x < nk && F.scr.sweep.neq[threadIdx.x]) atomicOr(&C.neq[threadIdx.x], 1u);
+    d4g_drain_stores();
+    if (lane == 0 && myDone) atomicAdd(&F.clDoneWg, myDone);
+    __syncthreads();
+    if (threadIdx.x == 0 && F.clDoneWg) { d4g_release_agent(); atomicAdd(&C.done, F.clDoneWg); }
+    __syncthreads();
+}
+
+// control: a fresh command slot (all threads; the slot's header and `n` tasks' accumulators are cleared, written through)
+D4F_TASK void d4f_cl_begin(int n) {
+    D4FLds& F = d4fLds;
+    __syncthreads();
+    if (threadIdx.x == 0) F.clEpoch++;
+    __syncthreads();
+    D4FClCmd& C = d4f_cl_cmd();
+    for (int i = threadIdx.x; i < (int)(offsetof(D4FClCmd, task) / 4); i += blockDim.x) st_sc1((uint32_t*)&C + i, 0u);
+    const int words = (int)(sizeof(D4FClTask) / 4);
+    for (int i = threadIdx.x; i < n * words; i += blockDim.x) st_sc1((uint32_t*)&C.task[0] + i, 0u);
+    d4g_drain_stores();
+    __syncthreads();
+}
+// control: post the command and work it off with whoever is there; returns when every item is done (all threads)
+D4F_TASK void d4f_cl_run() {
+    D4FLds& F = d4fLds;
+    D4FClCmd& C = d4f_cl_cmd();
+    d4g_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d4g_release_agent();
+        if (F.clEpoch <= D4F_CL_SLOTS) d4f_atomic_st(&F.cl->epoch, F.clEpoch);   // (beyond the slots: nobody is told, the control workgroup works alone)
+    }
+    __syncthreads();
+    d4f_cl_work();
+    if (threadIdx.x == 0) {
+        const int nItems = C.nItems;
+        long long spin = 0;   // (only items some resident workgroup has already taken are outstanding: microseconds; the bound is for a device gone wrong)
+        while (d4f_atomic_ld(&C.done) < nItems && ++spin < (1LL << 25)) d4g_sleep();
+        if (d4f_atomic_ld(&C.done) < nItems) { atomicAdd(F.c.errors, 1); F.fallback = 1; }
+        d4g_acquire_agent();
+    }
+    __syncthreads();
+}
+D4G_DEV void d4f_cl_set(int32_t* p, int v) { st_sc1((uint32_t*)p, (uint32_t)v); }
+
+D4F_TASK void d4f_cl_sweep() {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    const int nq = F.qn[D4F_Q_SWEEP] < D4F_QCAP_SWEEP ? F.qn[D4F_Q_SWEEP] : D4F_QCAP_SWEEP;
+    const int nWords = (int)b.maskWords;
+    for (int base = 0; base < nq; base += D4F_SWEEP_K) {
+        const int nk = nq - base < D4F_SWEEP_K ? nq - base : D4F_SWEEP_K;
+        d4f_cl_begin(0);
+        D4FClCmd& C = d4f_cl_cmd();
+        if ((int)threadIdx.x < nk) d4f_cl_set(&C.codes[threadIdx.x], F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + threadIdx.x]);
+        if (threadIdx.x == 0) {
+            d4f_cl_set(&C.cmd, D4F_CMD_SWEEP); d4f_cl_set(&C.nk, nk); d4f_cl_set(&C.nChunks, 1);
+            d4f_cl_set(&C.nItems, (nWords + D4F_CL_SWEEP_WORDS - 1) / D4F_CL_SWEEP_WORDS);
+        }
+        d4f_cl_run();
+        if ((int)threadIdx.x < nk) {
+            const int code = F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + threadIdx.x];
+            F.eEq[code] = C.neq[threadIdx.x] ? 0 : 1;
+            F.eState[code] = 2;
+        }
+        __syncthreads();
+    }
+}
+
+D4F_TASK void d4f_cl_apply_phase(int nq) {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nWords = (int)b.maskWords;
+    const int nChunks = (nWords + D4F_CL_CHUNK - 1) / D4F_CL_CHUNK;
+    for (int base = 0; base < nq; base += D4F_CL_MAXT) {
+        const int n = nq - base < D4F_CL_MAXT ? nq - base : D4F_CL_MAXT;
+        d4f_cl_begin(n);
+        D4FClCmd& C = d4f_cl_cmd();
+        if ((int)threadIdx.x < n) {
+            const uint32_t key = F.pass[F.qAll[d4f_qoff(D4F_Q_APPLY) + base + threadIdx.x]].key - 1;
+            const int leaf = (int)((key >> 16) & 1u);
+            int mNew = 0;
+            if (!leaf) { mNew = atomicAdd(&F.nMask, 1); if (mNew >= D4F_MAXM) { F.fallback = 1; mNew = 0; } }
+            D4FClTask& T = C.task[threadIdx.x];
+            d4f_cl_set(&T.m, (int)(key & 255u)); d4f_cl_set(&T.code, (int)((key >> 8) & 127u)); d4f_cl_set(&T.prune, (int)((key >> 15) & 1u));
+            d4f_cl_set(&T.leaf, leaf); d4f_cl_set(&T.mNew, mNew); d4f_cl_set(&T.rem, -1);
+        }
+        if (threadIdx.x == 0) { d4f_cl_set(&C.cmd, D4F_CMD_APPLY); d4f_cl_set(&C.nTasks, n); d4f_cl_set(&C.nChunks, nChunks); d4f_cl_set(&C.nItems, n * nChunks); }
+        d4f_cl_run();
+        for (int t = wave; t < n; t += nw) {
+            D4FWaveScr& W = F.scr.wave[wave & 7];
+            const D4FClTask& T = C.task[t];
+            D4FPassE& e = F.pass[F.qAll[d4f_qoff(D4F_Q_APPLY) + base + t]];
+            const int m = T.m, cnt = T.cnt;
+            int mOut = m, saved = 0;
+            if (cnt != 0 && (T.leaf || T.mNew != 0)) {
+                saved = T.saved;
+                if (!T.leaf) {
+                    for (int i = lane; i < D4G_HIST; i += 64) W.hist[i] = G.hist[(size_t)m * D4G_HIST + i] + (uint32_t)T.delta[i];
+                    d4g_wave_sync();
+                    if (lane == 0) F.maskFull[T.mNew] = F.maskFull[m];
+                    mOut = d4f_publish_mask(c, b, G, T.mNew, T.h1 + F.maskH1[m], T.h2 + F.maskH2[m], F.maskPop[m] + cnt, W.hist);
+                }
+            }
+            if (lane == 0) { e.mOut = (int16_t)mOut; e.saved = saved; d4f_fence_block(); e.st = 2; }
+        }
+        __syncthreads();
+    }
+}
+
+D4F_TASK void d4f_cl_least_phase(int nq) {
+    D4FLds& F = d4fLds;
+    D4F_CTX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nWords = (int)b.maskWords, nRef = (int)b.refCount;
+    const int nChunks = (nWords + D4F_CL_CHUNK - 1) / D4F_CL_CHUNK;
+    const uint32_t* stat = c.binStat + b.binStat;
+    for (int base = 0; base < nq; base += D4F_CL_MAXT) {
+        const int n = nq - base < D4F_CL_MAXT ? nq - base : D4F_CL_MAXT;
+        // ---- the walk: per length symbol, literal minus back-reference bits / records / bytes without a code of the unexpanded records ----
+        d4f_cl_begin(n);
+        D4FClCmd* C1 = &d4f_cl_cmd();
+        for (int t = wave; t < n; t += nw) {
+            const uint32_t key = F.least[F.qAll[d4f_qoff(D4F_Q_LEAST) + base + t]].key - 1;
+            const int m = (int)(key & 255u), code = (int)((key >> 8) & 127u), mode = (int)((key >> 15) & 1u);
+            const uint32_t full = F.maskFull[m];
+            int bSize = 0, bZ = 0, bCount = 0;
+            if (lane < D4G_NBINS) {
+                bSize = G.binBase[(size_t)code * 64 + lane];
+                bZ = G.binBase[(size_t)code * 64 + 32 + lane];
+                bCount = (int)stat[lane * D4G_BINSTRIDE + D4G_BIN_COUNT];
+            }
+            const bool isFull = lane < D4G_NBINS && ((full >> lane) & 1u);
+            const int popFull = wave_sum_i32(isFull ? bCount : 0);
+            const int via = F.maskPop[m] - popFull <= nRef - F.maskPop[m];
+            D4FClTask& T = C1->task[t];
+            if (lane < 32) {
+                d4f_cl_set(&T.bin[0][lane], via ? bSize : 0);
+                d4f_cl_set(&T.bin[2][lane], via ? bZ : 0);
+                d4f_cl_set(&T.bin[1][lane], via && !isFull ? bCount : 0);
+            }
+            if (lane == 0) {
+                d4f_cl_set(&T.m, m); d4f_cl_set(&T.code, code); d4f_cl_set(&T.mode, mode); d4f_cl_set(&T.via, via);
+                d4f_cl_set((int32_t*)&T.full, (int)full); d4f_cl_set(&T.rem, -1);
+            }
+        }
+        if (threadIdx.x == 0) { d4f_cl_set(&C1->cmd, D4F_CMD_LEAST_WALK); d4f_cl_set(&C1->nTasks, n); d4f_cl_set(&C1->nChunks, nChunks); d4f_cl_set(&C1->nItems, n * nChunks); }
+        d4f_cl_run();
+        // ---- the choice (DeflateBlockHuffman.java:373-458), then the expansion of the chosen symbol's records ----
+        d4f_cl_begin(n);
+        D4FClCmd* C2 = &d4f_cl_cmd();
+        if ((int)threadIdx.x < n) {
+            const D4FClTask& T = C1->task[threadIdx.x];
+            const int mode = T.mode;
+            int rem = -1, remSize = 0, remFreq = 0;
+            for (int i = 0; i < D4G_NBINS; i++) {
+                if (T.bin[1][i] > 0 && T.bin[2][i] == 0) {
+                    const bool doRem = mode == 1 ? T.bin[1][i] < remFreq : T.bin[0][i] < remSize;
+                    if (rem == -1 || doRem) { rem = i; remSize = T.bin[0][i]; remFreq = T.bin[1][i]; }
+                }
+            }
+            int mNew = 0;
+            if (rem >= 0) { mNew = atomicAdd(&F.nMask, 1); if (mNew >= D4F_MAXM) { F.fallback = 1; mNew = 0; } }
+            D4FClTask& U = C2->task[threadIdx.x];
+            d4f_cl_set(&U.m, T.m); d4f_cl_set(&U.code, T.code); d4f_cl_set(&U.mode, mode); d4f_cl_set((int32_t*)&U.full, (int)T.full);
+            d4f_cl_set(&U.rem, rem); d4f_cl_set(&U.mNew, mNew); d4f_cl_set(&U.pad0[0], remSize);
+        }
+        if (threadIdx.x == 0) { d4f_cl_set(&C2->cmd, D4F_CMD_LEAST_EXPAND); d4f_cl_set(&C2->nTasks, n); d4f_cl_set(&C2->nChunks, nChunks); d4f_cl_set(&C2->nItems, n * nChunks); }
+        d4f_cl_run();
+        for (int t = wave; t < n; t += nw) {
+            D4FWaveScr& W = F.scr.wave[wave & 7];
+            const D4FClTask& T = C2->task[t];
+            D4FLeastE& e = F.least[F.qAll[d4f_qoff(D4F_Q_LEAST) + base + t]];
+            const int m = T.m, rem = T.rem, mNew = T.mNew;
+            int mOut = m, dl = 0;
+            if (rem >= 0 && mNew != 0) {
+                const uint32_t* row = stat + rem * D4G_BINSTRIDE;
+                for (int i = lane; i < D4G_HIST; i += 64) W.hist[i] = G.hist[(size_t)m * D4G_HIST + i];
+                d4g_wave_sync();
+                for (int i = lane; i <= D4G_BIN_COUNT; i += 64) {
+                    const int moved = (int)row[i] - T.delta[i];
+                    if (!moved) continue;
+                    if (i < 256) atomicAdd(&W.hist[i], (unsigned)moved);
+                    else if (i < D4G_BIN_COUNT) atomicSub(&W.hist[D4G_NLIT + i - D4G_BIN_DIST], (unsigned)moved);
+                    else atomicSub(&W.hist[257 + rem], (unsigned)moved);
+                }
+                d4g_wave_sync();
+                if (lane == 0) F.maskFull[mNew] = T.full | (1u << rem);
+                mOut = d4f_publish_mask(c, b, G, mNew, T.h1 + F.maskH1[m], T.h2 + F.maskH2[m], F.maskPop[m] + T.cnt, W.hist);
+                dl = T.pad0[0];
+            }
+            if (lane == 0) { e.mOut = (int16_t)mOut; e.delta = dl; d4f_fence_block(); e.st = 2; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The kernel: one workgroup = one block, all its rounds
 // ---------------------------------------------------------------------------------------
 D4G_DEV D4FGlob d4f_glob(const D4GCtx& c, int blk) {
@@ -1655,7 +2082,7 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
     D4FLds& F = d4fLds;
     D4F_CTX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const D4GState* cur = state_ptr(c, c.active[blockIdx.x], 0);
+    const D4GState* cur = state_ptr(c, c.active[d4fLds.which], 0);
     __syncthreads();
     const int curType = cur->type;
     const int prog = curType == D4G_FIXED ? 1 : 0;
@@ -1694,7 +2121,8 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
         const uint64_t* bmask = c.binMask + b.binMask;
         const int nWords = (int)b.maskWords;
         unsigned nf = 0;
-        for (int i = threadIdx.x; i < D4G_NBINS * nWords; i += blockDim.x) {
+        if (nWords > 4096) nf = (1u << D4G_NBINS) - 1;   // (a long block: not worth the pass — no symbol is taken to be used up)
+        else for (int i = threadIdx.x; i < D4G_NBINS * nWords; i += blockDim.x) {
             const int bin = i / nWords, w = i - bin * nWords;
             if (bmask[(long long)bin * nWords + w] & ~m0[w]) nf |= 1u << bin;
         }
@@ -1765,7 +2193,7 @@ D4F_TASK bool d4f_select(long long best, D4GRoundResult* out) {
     D4FLds& F = d4fLds;
     D4F_CTX;
     const int wave = threadIdx.x >> 6;
-    D4GState* cur = state_ptr(c, c.active[blockIdx.x], 0);
+    D4GState* cur = state_ptr(c, c.active[d4fLds.which], 0);
     const long long curSize = F.curSize;
     const long long bestSize = best >> D4G_KEY_SEQ_BITS;
     const int seq = (int)(best & ((1 << D4G_KEY_SEQ_BITS) - 1));
@@ -1834,26 +2262,29 @@ D4F_TASK bool d4f_select(long long best, D4GRoundResult* out) {
     return true;
 }
 
-#ifndef D4F_WAVES_PER_SIMD
-#define D4F_WAVES_PER_SIMD 4
-#endif
-__global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_search_fused(D4GCtx cArg, D4FParams P) {
-#ifndef D4G_HOSTSIM
-    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
-#endif
+// what every workgroup of either kernel starts with: the block and its tables (`which` = index into the active list)
+__device__ __forceinline__ void d4f_block_init(const D4GCtx& cArg, const D4FParams& P, int which, D4FClArena* arena) {
     D4FLds& F = d4fLds;
-    if ((int)blockIdx.x >= cArg.nActive) return;
     for (int i = threadIdx.x; i < D4F_MAXC; i += blockDim.x) { F.eState[i] = 0; F.eEq[i] = 0; F.bbState[i] = 0; F.hsState[i] = 0; }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) F.codeHash[i] = 0;
     if (threadIdx.x == 0) {
-        const int blk = cArg.active[blockIdx.x];
+        const int blk = cArg.active[which];
         F.nCode = 2;
         F.regWords = P.regWords < 64 * D4F_NWR ? P.regWords : 64 * D4F_NWR;
         F.c = cArg;
         F.b = cArg.blocks[blk];
         F.G = d4f_glob(cArg, blk);
+        F.cl = arena;
+        F.clEpoch = 0;
+        F.which = which;
     }
     __syncthreads();
+}
+
+// the rounds of the block (all threads of its — control — workgroup)
+__device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
+    D4FLds& F = d4fLds;
+    const int which = F.which;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int rounds = 0, info = 0;
     // optional accounting (D4G_FUSED_STATS): [0,8) tasks per kind, [8,16) steps per kind, [16,24) cycles per kind, 24 advance,
@@ -1903,12 +2334,14 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
             const int nq = F.qn[which] < d4f_qcap(which) ? F.qn[which] : d4f_qcap(which);
             if (prof) { acc(which, nq); acc(8 + which, 1); tp = clock64(); }
             switch (which) {
-            case D4F_Q_SWEEP: d4f_sweep(); break;
+            case D4F_Q_SWEEP: if (F.cl) d4f_cl_sweep(); else d4f_sweep(); break;
             case D4F_Q_APPLY:
+                if (F.cl) { d4f_cl_apply_phase(nq); break; }
                 for (int t = wave; t < nq; t += nw) d4f_apply_task(F.qAll[d4f_qoff(D4F_Q_APPLY) + t]);
                 break;
             case D4F_Q_BINBASE: d4f_binbase(); break;
             case D4F_Q_LEAST:
+                if (F.cl) { d4f_cl_least_phase(nq); break; }
                 for (int t = wave; t < nq; t += nw) d4f_least_task(F.qAll[d4f_qoff(D4F_Q_LEAST) + t]);
                 break;
             case D4F_Q_TREE: {
@@ -1973,7 +2406,7 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
         for (int i = 0; i < nw; i++) best = F.red[i] < best ? F.red[i] : best;
         __syncthreads();
         tp = prof ? clock64() : 0;
-        if (!d4f_select(best, &P.results[(size_t)blockIdx.x * D4F_MAXROUNDS + rounds])) { info |= D4F_INFO_FALLBACK; break; }
+        if (!d4f_select(best, &P.results[(size_t)which * D4F_MAXROUNDS + rounds])) { info |= D4F_INFO_FALLBACK; break; }
         if (prof) acc(26, clock64() - tp);
         rounds++;
         if (!F.improved) break;
@@ -1981,5 +2414,54 @@ __global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_
     }
     __syncthreads();
     if (prof) acc(29, clock64() - tKernel);
-    if (threadIdx.x == 0) P.roundInfo[blockIdx.x] = rounds | info;
+    if (threadIdx.x == 0) P.roundInfo[which] = rounds | info;
+}
+
+#ifndef D4F_WAVES_PER_SIMD
+#define D4F_WAVES_PER_SIMD 4
+#endif
+__global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_search_fused(D4GCtx cArg, D4FParams P) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
+    if ((int)blockIdx.x >= cArg.nActive) return;
+    d4f_block_init(cArg, P, (int)blockIdx.x, nullptr);
+    d4f_block_rounds(P);
+}
+
+// One long block, many workgroups: workgroup 0 runs the search, the others work off the commands it posts (D4FClArena).
+__global__ void __launch_bounds__(512) D4G_WAVES_PER_SIMD(D4F_WAVES_PER_SIMD) k_search_cluster(D4GCtx cArg, D4FParams P, D4FClArena* arena, int which) {
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
+    D4FLds& F = d4fLds;
+    d4f_block_init(cArg, P, which, arena);
+    if (blockIdx.x == 0) {
+        d4f_block_rounds(P);
+        __syncthreads();
+        if (threadIdx.x == 0) { d4g_release_agent(); d4f_atomic_st(&arena->epoch, -1); }
+        return;
+    }
+    int seen = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int e = seen;
+            for (long long spin = 0; spin < (1LL << 23); spin++) {   // (a helper that waits this long — seconds — leaves: the control workgroup does not need it)
+                e = d4f_atomic_ld(&arena->epoch);
+                if (e != seen) break;
+                d4g_sleep();
+            }
+            if (e == seen) e = -1;
+            if (e > 0) d4g_acquire_agent();
+            F.misc[0] = e;
+        }
+        __syncthreads();
+        const int e = F.misc[0];
+        __syncthreads();
+        if (e < 0) break;
+        if (threadIdx.x == 0) F.clEpoch = e;   // (commands it missed were finished without it)
+        __syncthreads();
+        d4f_cl_work();
+        seen = e;
+    }
 }

@@ -82,6 +82,15 @@ static inline long long fused_max_refs(size_t nActive) {
     if (t) return atoll(t);
     return nActive >= 32 ? (1LL << 17) : (1LL << 14);
 }
+// A lone long block (more back-references than this) gets the whole device: k_search_cluster.  D4G_CLUSTER=0: never.
+static inline long long cluster_min_refs() {
+    static const long long v = getenv("D4G_CLUSTER_MIN_REFS") ? atoll(getenv("D4G_CLUSTER_MIN_REFS")) : (1LL << 15);
+    return v;
+}
+static inline bool cluster_enabled() {
+    const char* t = getenv("D4G_CLUSTER");
+    return !(t && t[0] == '0');
+}
 static inline int exec_persistent(int nActive = 0) {
     // read per call (not cached): the parity tests switch executors inside one process
     const char* t = getenv("D4G_EXEC");
@@ -573,7 +582,7 @@ struct Batch {
         try { rt_sync_all(); } catch (...) {}   // nothing may still be running on a block that goes back to the pool
         rt_free(dIn); rt_free(dTok); rt_free(dRefs); rt_free(dTokRef); rt_free(dBinStat); rt_free(dBinMask); rt_free(dHsMemo); rt_free(dRcMemo); rt_free(dPassMemo); rt_free(chunkPool.batches); rt_free(chunkPool.next); rt_free(dU); rt_free(dBlocks); rt_free(dStates);
         rt_free(dErr);
-        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads);
+        rt_free(dMasks); rt_free(dKeys); rt_free(dActive); rt_free(dResults); rt_free(dOut); rt_free(dStreams); rt_free(dSrc); rt_free(dReady); rt_free(dHeads); rt_free(dClArena);
     }
 
     int32_t* errors() {
@@ -868,7 +877,13 @@ struct Batch {
             stats.n_tokens += P.nTok;
             stats.bytes_decoded += P.nU;
             if (merge && needSlots && nHuff >= 2) {
-                for (int a = 0; a < 2; a++) s.arena[a] = add_block((int)si, s.tokBase, 0, s.refBase, 0, 0, 0, (s.nRef + 63) / 64 + 1, D4G_FIXED);
+                // (mask slots of an arena start on 128-byte lines and are whole lines long: the cluster kernel's workgroups hand
+                // mask words to each other and must never share a line between a slot already read and one still to be written)
+                for (int a = 0; a < 2; a++) {
+                    maskWordsTotal = (maskWordsTotal + 15) & ~15LL;
+                    binMaskWords = (binMaskWords + 15) & ~15LL;
+                    s.arena[a] = add_block((int)si, s.tokBase, 0, s.refBase, 0, 0, 0, (((s.nRef + 63) / 64 + 1) + 15) & ~15LL, D4G_FIXED);
+                }
                 // a finished merged block moves out of its arena (the two arenas are re-used by the next chain of merges)
                 s.commitMaskBase = maskWordsTotal;
                 maskWordsTotal += (s.nRef + 63) / 64 + (i64)P.blocks.size() + 2;
@@ -1048,6 +1063,18 @@ struct Batch {
             std::vector<std::vector<D4GRoundResult>> ch = run_fused(small, 1);
             for (size_t i = 0; i < small.size(); i++) res[smallPos[i]] = ch[i].at(0);
         }
+        if (!big.empty() && cluster_enabled()) {   // long merged blocks, one launch of the whole device each
+            std::vector<int> rest;
+            std::vector<size_t> restPos;
+            for (size_t i = 0; i < big.size(); i++) {
+                const D4GBlock& d = hBlocks[big[i]];
+                D4GRoundResult r;
+                if (d.refCount > cluster_min_refs() && (d.maskBase & 15) == 0 && (d.maskWords & 15) == 0 && (d.binMask & 15) == 0 && run_cluster(big[i], &r)) res[bigPos[i]] = r;
+                else { rest.push_back(big[i]); restPos.push_back(bigPos[i]); }
+            }
+            big.swap(rest);
+            bigPos.swap(restPos);
+        }
         if (!big.empty()) {
             std::vector<D4GRoundResult> r = run_round_legacy(big);
             for (size_t i = 0; i < big.size(); i++) res[bigPos[i]] = r[i];
@@ -1055,6 +1082,58 @@ struct Batch {
             stats.rounds++;
         }
         return res;
+    }
+    // One optimiseBlock round of one long block with every workgroup of the device (k_search_cluster).  false: the round did
+    // not fit the kernel's tables — the block is untouched and the caller uses another executor.
+    D4FClArena* dClArena = nullptr;
+    bool run_cluster(int blk, D4GRoundResult* out) {
+        Engine& E = engine();
+        rt().cur = 0;
+        if (!dClArena) dClArena = (D4FClArena*)rt_malloc(sizeof(D4FClArena));
+        rt_memset(dClArena, 0, 128);   // the epoch counter; every command slot is cleared by the control workgroup before use
+        int32_t one = blk;
+        rt_h2d(dActive, &one, sizeof(one));
+        D4GRoundResult* dRes = (D4GRoundResult*)rt_malloc(D4F_MAXROUNDS * sizeof(D4GRoundResult));
+        int32_t* dInfo = (int32_t*)rt_malloc(16);
+        D4GCtx c = make_ctx(E.progDyn, 1);
+        D4FParams P;
+        memset(&P, 0, sizeof(P));
+        P.ops[0] = E.progDyn.dOps; P.ops[1] = E.progFixed.dOps;
+        P.nOps[0] = (int)E.progDyn.ops.size(); P.nOps[1] = (int)E.progFixed.ops.size();
+        P.maxRounds = 1;
+        P.regWords = env_int("D4G_FUSED_REG_WORDS", 64 * D4F_NWR);
+        P.results = dRes;
+        P.roundInfo = dInfo;
+        P.stats = getenv("D4G_FUSED_STATS") ? E.dOpStats : nullptr;
+#ifdef D4G_HOSTSIM
+        const int wgs = 3, threads = std::max(128, state_block());
+#else
+        static const int wgs = env_int("D4G_CLUSTER_WGS", device_cus());
+        const int threads = 512;
+#endif
+        RtEvent e0, e1;
+        e0.record();
+        RT_LAUNCH(k_search_cluster, wgs, threads, c, P, dClArena, 0);
+        e1.record();
+        stats.kernel_launches++;
+        stats.state_launches++;
+        int32_t info = 0;
+        rt_d2h(&info, dInfo, sizeof(info));
+        D4GRoundResult r;
+        rt_d2h(&r, dRes, sizeof(r));
+        const float ms = rt_elapsed_ms(e0, e1);
+        msSearch += ms;
+        stats.ms_state_kernels += ms;
+        stats.state_tokens_per_round += hBlocks[blk].tokCount;
+        stats.state_bytes_per_round += hBlocks[blk].uLen;
+        rt_free(dRes); rt_free(dInfo);
+        if (getenv("D4G_DEBUG_ROUNDS")) fprintf(stderr, "cluster search: block of %lld back-references, %.3f ms%s\n", (long long)hBlocks[blk].refCount, ms, (info & D4F_INFO_FALLBACK) ? " (did not fit)" : "");
+        if ((info & D4F_INFO_FALLBACK) || (info & 0xffff) < 1) return false;
+        gpuType[blk] = r.newType;
+        stats.rounds_fused += 1;
+        stats.rounds_cluster += 1;
+        *out = r;
+        return true;
     }
     // Fused executor (k_search_fused): every block of `act` runs up to maxRounds optimiseBlock rounds, while it keeps
     // improving, inside one workgroup.  Returns each block's chain of round results.  A round that does not fit the
@@ -1450,6 +1529,7 @@ struct Batch {
                         d.uStart = cur.uStart;
                         d.uLen = cur.uLen + next.uLen;
                         d.maskWords = (d.refCount + 63) / 64;
+                        if (d.refCount > cluster_min_refs()) d.maskWords = (d.maskWords + 15) & ~15LL;   // whole 128-byte lines (zero padding): see layout_blocks
                         d.type = D4G_FIXED;
                         req->stream = si;
                         req->arena = ar;

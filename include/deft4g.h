@@ -74,6 +74,8 @@ typedef struct d4g_stats {
     int64_t rounds_fused, fused_fallbacks;
     /* rounds of the persistent executor that were run again by the level executor because a cross-kernel wait gave up */
     int64_t persist_fallbacks;
+    /* optimiseBlock rounds of long merged blocks run by the cluster kernel (the whole device on one block) */
+    int64_t rounds_cluster;
 } d4g_stats;
 
 /* Select the HIP device (one process per GPU) and create the library's stream.

@@ -381,3 +381,21 @@ def test_fused_executor_mask_tasks_in_their_any_length_form(sim, monkeypatch):
             assert b.result(i)["status"] == rc and b.output(i) == want and b.result(i)["saved_bits"] == saved, (i, merge)
         assert b.stats()["rounds_fused"] > 0
         b.close()
+
+
+def test_cluster_mode_in_the_emulator(sim, monkeypatch):
+    """k_search_cluster (many workgroups on one long merged block; the emulator runs the control workgroup first, so it works
+    every command off alone, then the helpers, which find the launch over): merge rounds forced through it, output == oracle."""
+    monkeypatch.setenv("D4G_FUSED_MAX_REFS", "0")
+    monkeypatch.setenv("D4G_CLUSTER_MIN_REFS", "0")
+    D, L = sim
+    c0 = zlib.compressobj(9, zlib.DEFLATED, -15)
+    t = synth.reptext(30000, 8)
+    multi = c0.compress(t[:9000]) + c0.flush(zlib.Z_FULL_FLUSH) + c0.compress(t[9000:20000]) + c0.flush(zlib.Z_FULL_FLUSH) + c0.compress(t[20000:]) + c0.flush()
+    ins = [multi, synth.make_stream(120000, 3)]
+    b = D.Batch(ins, lib=L).run(True)
+    for i, a in enumerate(ins):
+        rc, want, saved, _, _ = O.optimise(a, True)
+        assert b.output(i) == want and b.result(i)["saved_bits"] == saved
+    assert b.stats()["rounds_cluster"] > 0
+    b.close()
