@@ -836,7 +836,7 @@ D4G_DEV void d4f_wave_for_words(int nWords, int nRef, const uint4* rf, uint32_t*
         for (int j = 0; j < D4F_NWR; j++) {
             const int w = w0 + lane + 64 * j;
             uint64_t v = w < nWords ? sel(w) : 0ull;
-            if (w == nWords - 1 && (nRef & 63)) v &= (1ull << (nRef & 63)) - 1;
+            v &= d4g_valid_bits(w, nRef);
             d[j] = v;
         }
         d4f_wave_for_bits(d, rf + (size_t)w0 * 64, queue, fn);
@@ -1084,8 +1084,7 @@ D4F_TASK void d4f_least_task(int idx) {
 #pragma unroll
         for (int j = 0; j < D4F_NWR; j++) {
             const int w = lane + 64 * j;
-            uint64_t valid = w < nWords ? ~0ull : 0ull;
-            if (w == nWords - 1 && (nRef & 63)) valid = (1ull << (nRef & 63)) - 1;
+            const uint64_t valid = w < nWords ? d4g_valid_bits(w, nRef) : 0ull;
             d[j] = viaExpanded ? (mw[j] & ~fw[j]) : (~mw[j] & valid);
         }
         if (viaExpanded) {
@@ -1796,8 +1795,7 @@ D4F_TASK void d4f_cl_work() {
 #pragma unroll
             for (int j = 0; j < D4F_NWR; j++) {
                 const int w = w0 + lane + 64 * j;
-                uint64_t valid = w < nWords ? ~0ull : 0ull;
-                if (w == nWords - 1 && (nRef & 63)) valid = (1ull << (nRef & 63)) - 1;
+                const uint64_t valid = w < nWords ? d4g_valid_bits(w, nRef) : 0ull;
                 d[j] = tvia ? (mw[j] & ~xw[j]) : (~mw[j] & valid);
             }
             const int sgn = tvia ? -1 : 1;

@@ -77,15 +77,15 @@ static inline bool exec_fused() {
 // per block: unbeatable while there are blocks enough to fill the device, but a lone long block (the merge chain of one
 // big stream: 3.8 ms per round at 100 k back-references with the persistent executor's many workgroups, 7.5 ms fused) is
 // better served by op-level parallelism.  Measured on config 2 with merge on / 64 x 1 MiB with merge on.
-static inline long long fused_max_refs(size_t nActive) {
+static inline long long fused_max_refs(size_t nLong) {   // nLong: blocks of the round with more than 16384 back-references
     const char* t = getenv("D4G_FUSED_MAX_REFS");
     if (t) return atoll(t);
-    return nActive >= 32 ? (1LL << 17) : (1LL << 14);
+    return nLong >= 8 ? (1LL << 17) : (1LL << 14);
 }
 // A lone long block (more back-references than this) gets the whole device: k_search_cluster.  D4G_CLUSTER=0: never.
 static inline long long cluster_min_refs() {
-    static const long long v = getenv("D4G_CLUSTER_MIN_REFS") ? atoll(getenv("D4G_CLUSTER_MIN_REFS")) : (1LL << 15);
-    return v;
+    const char* t = getenv("D4G_CLUSTER_MIN_REFS");   // (read per call: the tests switch it inside one process)
+    return t ? atoll(t) : (1LL << 14);
 }
 static inline bool cluster_enabled() {
     const char* t = getenv("D4G_CLUSTER");
@@ -1055,8 +1055,12 @@ struct Batch {
         std::vector<D4GRoundResult> res(act.size());
         std::vector<int> small, big;
         std::vector<size_t> smallPos, bigPos;
+        // Blocks of up to 16384 back-references: one workgroup each (fused).  Longer ones: when there are many of them they
+        // still fill the device one workgroup each; a few long blocks get the whole device one after the other (cluster).
+        size_t nLong = 0;
+        for (int k : act) nLong += hBlocks[k].refCount > (1LL << 14);
         for (size_t i = 0; i < act.size(); i++) {
-            if (hBlocks[act[i]].refCount <= fused_max_refs(act.size())) { small.push_back(act[i]); smallPos.push_back(i); }
+            if (hBlocks[act[i]].refCount <= fused_max_refs(nLong)) { small.push_back(act[i]); smallPos.push_back(i); }
             else { big.push_back(act[i]); bigPos.push_back(i); }
         }
         if (!small.empty()) {
@@ -1418,8 +1422,10 @@ struct Batch {
         if (exec_fused()) {   // all rounds of a block inside one workgroup; blocks the fused executor does not take follow below
             std::vector<int> fa, rest;
             std::vector<std::pair<int, int>> fo, ro;
+            size_t nLong = 0;
+            for (int k : act) nLong += hBlocks[k].refCount > (1LL << 14);
             for (size_t i = 0; i < act.size(); i++) {
-                if (hBlocks[act[i]].refCount <= fused_max_refs(act.size())) { fa.push_back(act[i]); fo.push_back(owner[i]); }
+                if (hBlocks[act[i]].refCount <= fused_max_refs(nLong)) { fa.push_back(act[i]); fo.push_back(owner[i]); }
                 else { rest.push_back(act[i]); ro.push_back(owner[i]); }
             }
             if (!fa.empty()) {

@@ -157,6 +157,13 @@ D4G_DEV bool d4g_ref_expanded(const uint64_t* mask, uint32_t ref, long long refS
     uint32_t r = ref - (uint32_t)refStart;
     return (mask[r >> 6] >> (r & 63)) & 1;
 }
+// the bits of mask word w that stand for records (a mask may be longer than its records: whole cache lines, zero padded)
+D4G_DEV uint64_t d4g_valid_bits(int w, int nRef) {
+    const long long lo = (long long)w * 64;
+    if (lo + 64 <= nRef) return ~0ull;
+    if (lo >= nRef) return 0ull;
+    return (1ull << (nRef & 63)) - 1;
+}
 D4G_DEV D4GState* state_ptr(const D4GCtx& c, int blockIdx_, int slot) { return c.states + ((long long)blockIdx_ * c.slotsPerBlock + slot); }
 
 D4G_DEV void wg_copy_words(uint32_t* dst, const uint32_t* src, int n) {
@@ -584,7 +591,7 @@ D4G_DEV void wave_for_selected(int wave, int nw, int nWords, int nRef, const uin
     int pending = 0;
     for (int w = wave; w < nWords; w += nw) {
         unsigned long long m = sel(w);
-        if (w == nWords - 1 && (nRef & 63)) m &= (1ULL << (nRef & 63)) - 1;
+        m &= d4g_valid_bits(w, nRef);
         int n = __popcll(m);
         if ((m >> lane) & 1) queue[pending + __popcll(m & ((1ULL << lane) - 1))] = (uint32_t)(w * 64 + lane);
         pending += n;

@@ -260,3 +260,17 @@ def test_config5_mix_through_the_sharded_path(D):
     for i, (s, o, w) in enumerate(zip(streams, outs, want)):
         assert o == (w[1] if w[0] == 0 else None), (i, items[i][0], len(items[i][1]))
         assert zlib.decompress(o if o is not None else s, -15) == items[i][1]
+
+
+def test_cluster_mode_on_a_merge_chain_vs_oracle(D):
+    """A 4 MiB stream with merge on: its merge chain grows one block past the length at which a lone block gets the whole
+    device (k_search_cluster: the control workgroup's commands worked off by every workgroup); output == the oracle's, and
+    == the persistent executor's with D4G_CLUSTER=0."""
+    a = synth.make_stream(4 << 20, 77)
+    b = D.Batch([a]).run(True)
+    st = b.stats()
+    got, saved = b.output(0), b.result(0)["saved_bits"]
+    b.close()
+    assert st["rounds_cluster"] > 0
+    rc, want, osaved, _, _ = O.optimise(a, True)
+    assert rc == 0 and got == want and saved == osaved
