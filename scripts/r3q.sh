@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for cfg in "D4G_CLUSTER=1" "D4G_EXEC=auto"; do
-env $cfg timeout -k 10 120 python - <<PY
+env $cfg timeout -k 10 400 python - >> gpurun_out/r3q_repro.log 2>&1 <<PY
 import sys, pickle, os
 sys.path.insert(0,'tests')
 import deft4j_amd as D, oracle_lib as O
@@ -14,5 +14,4 @@ except Exception as e:
     print("$cfg", "FAILED", e, flush=True)
 PY
 done
-timeout -k 10 200 python scripts/gpu_fuzz.py 150 99 --big > gpurun_out/r3q_fuzzbig.log 2>&1; tail -2 gpurun_out/r3q_fuzzbig.log
-timeout -k 10 150 python scripts/gpu_fuzz.py 100 98 > gpurun_out/r3q_fuzz.log 2>&1; tail -2 gpurun_out/r3q_fuzz.log
+cat gpurun_out/r3q_repro.log
