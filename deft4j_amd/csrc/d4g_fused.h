@@ -2305,12 +2305,30 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
         // ---- the program ----
         long long bestKey = D4G_KEY_NONE;
         int guard = 0;
+        int lastWhich = -1;   // the kind of task that ran since the last advance (-1: look at every op)
+        // An op past its first step waits for a memo entry, and entries only fill in when tasks of their kind run: such an op
+        // is looked at again only after a step of a kind it can be waiting for.
+        auto may_move = [&](int kind, int stage) -> bool {
+            if (stage == 0 || lastWhich < 0) return true;
+            switch (kind) {
+            case OP_HDRSEARCH: return lastWhich == D4F_Q_HS;
+            case OP_POST: case OP_PRUNEHDR: return lastWhich == D4F_Q_HDR;
+            case OP_OPT: return lastWhich == D4F_Q_APPLY || lastWhich == D4F_Q_HDR;
+            case OP_RECODE: case OP_RECODE_FULL: return stage == 1 ? lastWhich == D4F_Q_APPLY : lastWhich == D4F_Q_TREE;
+            case OP_LEAST: return lastWhich == D4F_Q_LEAST;
+            case OP_TOFIXED_OPT: return stage == 1 ? lastWhich == D4F_Q_FIXDOT : lastWhich == D4F_Q_APPLY;
+            default: return true;
+            }
+        };
         for (int iter = 0;; iter++) {
             bool prog2 = false;
             tp = prof ? clock64() : 0;
-            for (int i = threadIdx.x, n = 0; i < nOps; i += blockDim.x, n++)
-                if (F.opStage[i] != 255 && F.slotReady[n == 0 ? myOp0.src : n == 1 ? myOp1.src : ops[i].src])
-                    prog2 |= d4f_advance_op(n == 0 ? myOp0 : n == 1 ? myOp1 : ops[i], i, &bestKey);
+            for (int i = threadIdx.x, n = 0; i < nOps; i += blockDim.x, n++) {
+                const int st = F.opStage[i];
+                if (st == 255) continue;
+                const D4GOp& o = n == 0 ? myOp0 : n == 1 ? myOp1 : ops[i];
+                if (F.slotReady[o.src] && may_move(o.kind, st)) prog2 |= d4f_advance_op(o, i, &bestKey);
+            }
             if (prog2) F.progress[iter & 1] = 1;
             __syncthreads();
             if (prof) { acc(24, clock64() - tp); acc(28, 1); }
@@ -2324,6 +2342,7 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
             __syncthreads();
             if (fb) break;
             if (nDone >= nOps) break;
+            lastWhich = which;
             if (which < 0) {
                 if (!progressed && ++guard > 4) { if (threadIdx.x == 0) { atomicAdd(F.c.errors, 1); F.fallback = 1; } __syncthreads(); break; }
                 continue;

@@ -1,0 +1,54 @@
+// How long does one wave take to rebuild a literal/length tree of ~56 used symbols?  (the search's critical chain)
+#include "../../../deft4j_amd/csrc/d4g_device.h"
+#include <cstdio>
+#include <vector>
+#ifndef VAR_OFFER
+#define VAR_OFFER 0
+#endif
+#ifndef VAR_POLL
+#define VAR_POLL 0
+#endif
+#include "tree64_exp.h"
+typedef TreeMem<uint64_t, uint16_t, D4G_NLIT, 16, true> LitTree;
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+__global__ void k_tree(const uint32_t* histG, uint8_t* lensG, long long* ticks, int reps) {
+    __shared__ alignas(16) unsigned char mem[(LitTree::bytes(1) + 15) & ~15];
+    __shared__ uint32_t hist[D4G_NLIT];
+    __shared__ uint8_t lens[D4G_NLIT];
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < D4G_NLIT; i += 64) { hist[i] = histG[i]; lens[i] = 0; }
+    __syncthreads();
+    LitTree tm; tm.carve(mem, 1);
+    long long t0 = clock64();
+    int err = 0;
+    for (int r = 0; r < reps; r++)
+        err |= tree64_exp<(D4G_NLIT + 63) / 64>(tm, 286, 15, [&](int i) { return hist[i]; }, [&](int v, int len) { lens[v] = (uint8_t)len; });
+    long long t1 = clock64();
+    for (int i = lane; i < D4G_NLIT; i += 64) lensG[i] = lens[i];
+    if (lane == 0) { ticks[0] = t1 - t0; ticks[1] = err; for (int k = 0; k < 4; k++) ticks[2 + k] = g_t[k]; ticks[6] = wall_clock64(); }
+}
+int main() {
+    std::vector<uint32_t> h(D4G_NLIT, 0);
+    // 55 used literals with a text-like distribution + 256 + a few length symbols
+    unsigned s = 12345;
+    int used = 0;
+    for (int i = 32; i < 127 && used < 48; i += 2) { s = s * 1664525u + 1013904223u; h[i] = 1 + (s >> 20) % 3000; used++; }
+    h[256] = 1;
+    for (int i = 257; i < 265; i++) { s = s * 1664525u + 1013904223u; h[i] = 1 + (s >> 20) % 500; }
+    uint32_t* dh; uint8_t* dl; long long* dt;
+    hipMalloc(&dh, 4 * D4G_NLIT); hipMalloc(&dl, D4G_NLIT); hipMalloc(&dt, 64);
+    hipMemcpy(dh, h.data(), 4 * D4G_NLIT, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 3; rep++) {
+        const int reps = 200;
+        hipLaunchKernelGGL(k_tree, dim3(1), dim3(64), 0, 0, dh, dl, dt, reps);
+        hipDeviceSynchronize();
+        long long t[8]; hipMemcpy(t, dt, 64, hipMemcpyDeviceToHost);
+        std::vector<uint8_t> l(D4G_NLIT); hipMemcpy(l.data(), dl, D4G_NLIT, hipMemcpyDeviceToHost);
+        unsigned ck = 0; for (int i = 0; i < D4G_NLIT; i++) ck = ck * 31 + l[i];
+        printf("stages (cycles per tree): setup %.0f offers %.0f merges %.0f depths %.0f\n", (double)t[2]/reps/(rep+1), (double)t[3]/reps/(rep+1), (double)t[4]/reps/(rep+1), (double)t[5]/reps/(rep+1));
+        printf("offer %d poll %d: %.0f cycles per tree (57 leaves), err %lld, lens checksum %08x\n", VAR_OFFER, VAR_POLL, (double)t[0] / reps, t[1], ck);
+    }
+    return 0;
+}
