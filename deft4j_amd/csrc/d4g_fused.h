@@ -194,6 +194,7 @@ struct D4FSweepScr {
     uint16_t lc[D4F_SWEEP_K][256];
     uint8_t cl[D4F_SWEEP_K][64];
     uint32_t neq[D4F_SWEEP_K];
+    unsigned long long stage[8][D4F_SWEEP_K][2][16];   // per wave: the E-set words of the group in hand (d4f_sweep_group)
 };
 struct D4FHsScr {
     D4GHdrLds H;
@@ -628,8 +629,11 @@ __device__ __forceinline__ void d4f_sweep_tables(const int32_t* codes, int nk) {
     if (threadIdx.x < D4F_SWEEP_K) S.neq[threadIdx.x] = 0;
     __syncthreads();
 }
-// one wave: mask words wLo, wLo + step, ... below wHi of the E-sets of the table's codes (S.neq[k] is set where E0 != E1)
-__device__ __forceinline__ void d4f_sweep_words(const int32_t* codes, int nk, int wLo, int wHi, int step) {
+// one wave: the E-set words [w0, w0 + nW) (nW <= 16 consecutive words) of the table's codes (S.neq[k] is set where E0 != E1).
+// The words of a group are collected in registers — lane i keeps word w0 + i of every code — and leave as one contiguous
+// store per code and comparison mode instead of one 8-byte store per word.
+#define D4F_SWEEP_GROUP 16
+__device__ __forceinline__ void d4f_sweep_group(const int32_t* codes, int nk, int w0, int nW) {
     D4FLds& F = d4fLds;
     D4F_CTX;
     const int lane = threadIdx.x & 63;
@@ -637,12 +641,13 @@ __device__ __forceinline__ void d4f_sweep_words(const int32_t* codes, int nk, in
     const uint4* rf = c.refs + b.refStart;
     const uint32_t* Uw = (const uint32_t*)(c.U + b.uBase);
     const int nRef = (int)b.refCount;
+    unsigned long long (*stage)[2][16] = S.stage[(threadIdx.x >> 6) & 7];
     uint4 nrec = make_uint4(0u, 0u, 0u, 0u);
-    if (wLo < wHi) { int r = wLo * 64 + lane; if (r < nRef) nrec = rf[r]; }
-    for (int w = wLo; w < wHi; w += step) {
+    if (nW > 0) { int r = w0 * 64 + lane; if (r < nRef) nrec = rf[r]; }
+    for (int i = 0; i < nW; i++) {
         const uint4 rec = nrec;
         nrec = make_uint4(0u, 0u, 0u, 0u);
-        if (w + step < wHi) { int r = (w + step) * 64 + lane; if (r < nRef) nrec = rf[r]; }
+        if (i + 1 < nW) { int r = (w0 + i + 1) * 64 + lane; if (r < nRef) nrec = rf[r]; }
         const uint32_t a = rec.x;
         const int len = ref_len(a);
         const int ls = ref_lsym(a) - 257, ds = ref_dsym(a), eb = ref_ebits(a);
@@ -669,13 +674,20 @@ __device__ __forceinline__ void d4f_sweep_words(const int32_t* codes, int nk, in
                 e0 = t < cost;
             }
             const unsigned long long b1 = __ballot(e1), b0 = __ballot(e0);
-            if (lane == 0) {
-                d4f_eset(c, b, codes[k], 0)[w] = b0;
-                d4f_eset(c, b, codes[k], 1)[w] = b1;
-                if (b0 != b1) S.neq[k] = 1;
-            }
+            if (lane == 0) { stage[k][0][i] = b0; stage[k][1][i] = b1; }
         }
     }
+    d4g_wave_sync();
+    for (int k = 0; k < nk; k++) {
+        unsigned long long v0 = 0, v1 = 0;
+        if (lane < nW) {
+            v0 = stage[k][0][lane]; v1 = stage[k][1][lane];
+            d4f_eset(c, b, codes[k], 0)[w0 + lane] = v0;
+            d4f_eset(c, b, codes[k], 1)[w0 + lane] = v1;
+        }
+        if (__ballot(v0 != v1) && lane == 0) S.neq[k] = 1;
+    }
+    d4g_wave_sync();
 }
 D4F_TASK void d4f_sweep() {
     D4FLds& F = d4fLds;
@@ -690,7 +702,9 @@ D4F_TASK void d4f_sweep() {
         __syncthreads();
         if ((int)threadIdx.x < nk) codes[threadIdx.x] = F.qAll[d4f_qoff(D4F_Q_SWEEP) + base + threadIdx.x];
         d4f_sweep_tables(codes, nk);
-        d4f_sweep_words(codes, nk, wave, nWords, nw);
+        // groups of consecutive words, as many as keep every wave busy (whole cache lines when the block is long enough)
+        const int gw = nWords >= nw * D4F_SWEEP_GROUP ? D4F_SWEEP_GROUP : nWords >= nw * 8 ? 8 : 4;
+        for (int w0 = wave * gw; w0 < nWords; w0 += nw * gw) d4f_sweep_group(codes, nk, w0, nWords - w0 < gw ? nWords - w0 : gw);
         __syncthreads();
         if ((int)threadIdx.x < nk) {
             F.eEq[codes[threadIdx.x]] = S.neq[threadIdx.x] ? 0 : 1;
@@ -1734,7 +1748,7 @@ D4F_TASK void d4f_cl_work() {
         myDone++;
         if (cmd == D4F_CMD_SWEEP) {
             const int w0 = item * D4F_CL_SWEEP_WORDS;
-            d4f_sweep_words(C.codes, nk, w0, w0 + D4F_CL_SWEEP_WORDS < nWords ? w0 + D4F_CL_SWEEP_WORDS : nWords, 1);
+            d4f_sweep_group(C.codes, nk, w0, w0 + D4F_CL_SWEEP_WORDS < nWords ? D4F_CL_SWEEP_WORDS : nWords - w0);
             continue;
         }
         const int t = item / nChunks, w0 = (item - t * nChunks) * D4F_CL_CHUNK;
