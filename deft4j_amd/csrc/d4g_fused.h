@@ -222,6 +222,8 @@ struct D4FLds {
     uint32_t maskFull[D4F_MAXM];      // length symbols known to have every record expanded (bit per symbol): they take no part in least-expensive pruning
     alignas(4) uint16_t maskHash[512];           // id + 1 by maskH1
     uint16_t maskStep[D4F_MAXM];      // step in which the mask was published (content is compared only with masks of earlier steps: their words are visible)
+    uint16_t maskHH[D4F_MAXM];        // hash of the mask's histogram: masks with equal histograms share one Huffman rebuild (checked entry by entry)
+    int32_t treeCand[2][D4F_QCAP_TREE]; // tree step: per queued mask, an equal-histogram mask whose rebuild stands / an earlier queue position
     int16_t defHdr[D4F_MAXC];         // header id of the code's default header, -1: not built
     uint16_t qAll[D4F_QTOTAL];
     int32_t qn[D4F_NQ];
@@ -758,6 +760,14 @@ D4G_DEV void d4f_rec_to_hist(uint32_t* hist, const uint8_t* Ub, const uint4& rv)
     }
 }
 
+// hash of a histogram (one wave; hist[] readable by every lane)
+D4G_DEV uint16_t d4f_hist_hash(const uint32_t* hist) {
+    const int lane = threadIdx.x & 63;
+    unsigned h = 0;
+    for (int i = lane; i < D4G_HIST; i += 64) h += (hist[i] + 0x9e37u) * (2u * (unsigned)i + 1u) * 0x9E3779B1u;
+    h = (unsigned)wave_sum_i32((int)h);
+    return (uint16_t)(h ^ (h >> 16));
+}
 // A new mask (words already written to pool slot `mNew`, hashes relative to mask 0 in h1/h2, histogram in W.hist) gets
 // its id: an earlier mask with the same content (hashes, then every word) is reused.  One wave; returns the id.
 D4G_DEV int d4f_publish_mask(const D4GCtx& c, const D4GBlock& b, const D4FGlob& G, int mNew, unsigned long long h1, unsigned long long h2,
@@ -781,7 +791,9 @@ D4G_DEV int d4f_publish_mask(const D4GCtx& c, const D4GBlock& b, const D4FGlob& 
     }
     if (found >= 0) return found;
     for (int i = lane; i < D4G_HIST; i += 64) G.hist[(size_t)mNew * D4G_HIST + i] = hist[i];
+    const uint16_t hh = d4f_hist_hash(hist);
     if (lane == 0) {
+        F.maskHH[mNew] = hh;
         F.maskH1[mNew] = h1; F.maskH2[mNew] = h2; F.maskPop[mNew] = pop; F.maskStep[mNew] = (uint16_t)F.step;
         uint32_t kk = (uint32_t)(h1 >> 40) & 511u;
         for (int probe = 0; probe < 512; probe++, kk = (kk + 1) & 511u) {
@@ -2182,6 +2194,10 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
         }
         if (lane == 0) F.misc[2] = code;
     }
+    if (wave == 1 || blockDim.x == 64) {
+        const uint16_t hh = d4f_hist_hash(cur->hist);
+        if (lane == 0) F.maskHH[0] = hh;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         c1.nLit = 0; c1.nDist = 0; c1.type = D4G_FIXED; c1.err = 0;
@@ -2376,24 +2392,73 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
                 for (int t = wave; t < nq; t += nw) d4f_least_task(F.qAll[d4f_qoff(D4F_Q_LEAST) + t]);
                 break;
             case D4F_Q_TREE: {
+                // Masks with the same histogram have the same rebuild: a queued mask whose histogram equals that of a mask whose
+                // rebuild stands, or of a mask earlier in the queue, takes that one's result instead of being built.
+                uint16_t* Q = &F.qAll[d4f_qoff(D4F_Q_TREE)];
+                const int nMaskNow = F.nMask;
+                if ((int)threadIdx.x < nq) { F.treeCand[0][threadIdx.x] = 0x7fffffff; F.treeCand[1][threadIdx.x] = 0x7fffffff; }
+                __syncthreads();
+                for (int i = threadIdx.x; i < nq * nMaskNow; i += blockDim.x) {
+                    const int t = i / nMaskNow, mp = i - t * nMaskNow, m = Q[t];
+                    if (mp != m && F.treeSt[mp] == 2 && F.maskHH[mp] == F.maskHH[m]) atomicMin(&F.treeCand[0][t], mp);
+                }
+                for (int i = threadIdx.x; i < nq * nq; i += blockDim.x) {
+                    const int t = i / nq, j = i - t * nq;
+                    if (j < t && F.maskHH[Q[j]] == F.maskHH[Q[t]]) atomicMin(&F.treeCand[1][t], j);
+                }
+                __syncthreads();
+                // the candidate's histogram entry by entry (one wave per queued mask); treeCand[0][t] becomes the mask to copy from, or -1
+                for (int t = wave; t < nq; t += nw) {
+                    const int m = Q[t];
+                    int from = F.treeCand[0][t] != 0x7fffffff ? F.treeCand[0][t] : F.treeCand[1][t] != 0x7fffffff ? (int)Q[F.treeCand[1][t]] : -1;
+                    if (from >= 0) {
+                        int diff = 0;
+                        for (int i = lane; i < D4G_HIST; i += 64) diff |= F.G.hist[(size_t)m * D4G_HIST + i] != F.G.hist[(size_t)from * D4G_HIST + i];
+                        if (__ballot(diff)) from = -1;
+                    }
+                    d4g_wave_sync();
+                    if (lane == 0) F.treeCand[0][t] = from;
+                }
+                __syncthreads();
+                // the masks to build move to the front of the queue; the others are listed with the mask they copy, in queue order
+                if (threadIdx.x == 0) {   // (treeCand[1] is free again: mask << 16 | the mask it copies)
+                    int nu = 0, na = 0;
+                    for (int t = 0; t < nq; t++) {
+                        const int m = Q[t], from = F.treeCand[0][t];
+                        if (from < 0) Q[nu++] = (uint16_t)m;
+                        else F.treeCand[1][na++] = (m << 16) | from;
+                    }
+                    F.misc[3] = nu;
+                }
+                __syncthreads();
+                const int nu = F.misc[3];
+                if (prof) acc(38, nq - nu);
                 const int nts = (nw >> 1) < D4F_TREE_SLOTS ? (nw >> 1) : D4F_TREE_SLOTS;   // (at least two waves per workgroup)
-                for (int t0 = 0; t0 < nq; t0 += nts) {
+                for (int t0 = 0; t0 < nu; t0 += nts) {
                     const int ts = wave >> 1;
                     long long tq = prof ? clock64() : 0;
-                    if (ts < nts && t0 + ts < nq) {
-                        const int m = F.qAll[d4f_qoff(D4F_Q_TREE) + t0 + ts];
+                    if (ts < nts && t0 + ts < nu) {
+                        const int m = Q[t0 + ts];
                         if (wave & 1) d4f_tree_dist(ts, m); else d4f_tree_lit(ts, m);
                     }
                     if (prof) { acc(33, clock64() - tq); tq = clock64(); }
                     __syncthreads();
                     if (prof) { acc(34, clock64() - tq); tq = clock64(); }
-                    if (ts < nts && t0 + ts < nq && !(wave & 1)) d4f_tree_header(ts);
+                    if (ts < nts && t0 + ts < nu && !(wave & 1)) d4f_tree_header(ts);
                     __syncthreads();
                     if (prof) { acc(35, clock64() - tq); tq = clock64(); }
                     if (wave == 0)
-                        for (int t = 0; t < nts && t0 + t < nq; t++) d4f_tree_publish(t);
+                        for (int t = 0; t < nts && t0 + t < nu; t++) d4f_tree_publish(t);
                     __syncthreads();
                     if (prof) { acc(36, clock64() - tq); acc(37, 1); }
+                }
+                if (threadIdx.x == 0) {   // in queue order: a mask copied from an earlier one of this queue finds it finished
+                    for (int k = 0; k < nq - nu; k++) {
+                        const int m = F.treeCand[1][k] >> 16, from = F.treeCand[1][k] & 0xffff;
+                        F.treeC[m] = F.treeC[from]; F.treeLit[m] = F.treeLit[from];
+                        d4f_fence_block();
+                        F.treeSt[m] = 2;
+                    }
                 }
                 break;
             }
@@ -2444,7 +2509,13 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
         if (rounds >= P.maxRounds || rounds >= D4F_MAXROUNDS) { info |= D4F_INFO_MORE; break; }
     }
     __syncthreads();
-    if (prof) acc(29, clock64() - tKernel);
+    if (prof) {   // [39] the slowest block, [40, 64) blocks by duration (0.5 M cycles per class), refs of the blocks in the slowest classes in [..]
+        const long long dt = clock64() - tKernel;
+        acc(29, dt);
+        atomicMax((unsigned long long*)&P.stats[39], (unsigned long long)dt);
+        const int cls = (int)(dt / 500000) < 23 ? (int)(dt / 500000) : 23;
+        acc(40 + cls, 1);
+    }
     if (threadIdx.x == 0) P.roundInfo[which] = rounds | info;
 }
 

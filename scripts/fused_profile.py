@@ -26,5 +26,6 @@ for k, nm in enumerate(names):
         print("%-8s tasks/round %6.1f  phases/round %5.1f  cycles/phase %8.0f  share %5.1f %%" % (nm, buf[k] / rounds, buf[8 + k] / rounds, buf[16 + k] / buf[8 + k], 100.0 * buf[16 + k] / tot))
 print("advance  %5.1f %%   set-up %5.1f %%   selection %5.1f %%" % (100.0 * buf[24] / tot, 100.0 * buf[25] / tot, 100.0 * buf[26] / tot))
 if buf[37]:
-    print("tree batch (mean cycles): own literal tree %.0f  wait for the others %.0f  header %.0f  publish %.0f  (%.1f batches per round)" % (buf[33] / buf[37], buf[34] / buf[37], buf[35] / buf[37], buf[36] / buf[37], buf[37] / rounds))
+    print("tree batch (mean cycles): own literal tree %.0f  wait for the others %.0f  header %.0f  publish %.0f  (%.1f batches per round, %.1f rebuilds per round taken from an equal histogram)" % (buf[33] / buf[37], buf[34] / buf[37], buf[35] / buf[37], buf[36] / buf[37], buf[37] / rounds, buf[38] / rounds))
 print("ids per round: masks %.1f codes %.1f headers %.1f" % (buf[30] / rounds, buf[31] / rounds, buf[32] / rounds))
+print("slowest block %.0f cycles (%.2f ms); blocks by duration (0.21 ms classes): %s" % (buf[39], buf[39] / 2.4e6, " ".join(str(buf[40 + k]) for k in range(24))))
