@@ -589,6 +589,25 @@ struct Batch {
         if (!dErr) { dErr = (int32_t*)rt_malloc(16); rt_memset(dErr, 0, 16); }
         return dErr;
     }
+    // What only the level / persistent executors use (candidate keys, slot epochs, queue heads, the three memo tables): made
+    // on their first use — a batch the fused executor handles alone never allocates or clears them.
+    size_t legacyBlocks = 0;
+    long long legacyPassMemoWords = 0;
+    void ensure_legacy_tables() {
+        if (dKeys || !legacyBlocks) return;
+        Engine& E = engine();
+        const size_t nb = legacyBlocks;
+        dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
+        dReady = (int32_t*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(int32_t));
+        rt_memset(dReady, 0, nb * (size_t)slotsAlloc * sizeof(int32_t));
+        dHeads = (unsigned*)rt_malloc(64);
+        dHsMemo = (D4GHsMemo*)rt_malloc(nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
+        rt_memset(dHsMemo, 0, nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
+        dPassMemo = (uint64_t*)rt_malloc((size_t)legacyPassMemoWords * 8 + 64);
+        rt_memset(dPassMemo, 0, (size_t)legacyPassMemoWords * 8 + 64);
+        dRcMemo = (D4GRecodeMemo*)rt_malloc(nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
+        rt_memset(dRcMemo, 0, nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
+    }
     D4GCtx make_ctx(const Program& P, int nActive) {
         Engine& E = engine();
         D4GCtx c;
@@ -904,12 +923,9 @@ struct Batch {
             rt_h2d(dBlocks, hBlocks.data(), nb * sizeof(D4GBlock));
             dStates = (D4GState*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(D4GState));
             dMasks = (uint64_t*)rt_malloc((size_t)maskWordsTotal * 8 + 64);
-            if (needSlots) {
-                dKeys = (long long*)rt_malloc(nb * (size_t)E.maxOps * sizeof(long long));
-                dReady = (int32_t*)rt_malloc(nb * (size_t)slotsAlloc * sizeof(int32_t));
-                rt_memset(dReady, 0, nb * (size_t)slotsAlloc * sizeof(int32_t));
-                dHeads = (unsigned*)rt_malloc(64);
-            }
+            legacyBlocks = needSlots ? nb : 0;
+            legacyPassMemoWords = passMemoWords;
+            if (needSlots && !exec_fused()) ensure_legacy_tables();   // (the fused executor's batches make them when a block first falls back)
             dActive = (int32_t*)rt_malloc(nb * sizeof(int32_t));
             dResults = (D4GRoundResult*)rt_malloc(nb * sizeof(D4GRoundResult));
             // mask 0 of every block starts empty (no back-reference expanded); the writer reads it even when no search runs
@@ -919,12 +935,6 @@ struct Batch {
                 dBinMask = (uint64_t*)rt_malloc((size_t)binMaskWords * 8 + 64);
                 rt_memset(dBinStat, 0, nb * (size_t)D4G_NBINS * D4G_BINSTRIDE * 4);
                 rt_memset(dBinMask, 0, (size_t)binMaskWords * 8 + 64);
-                dHsMemo = (D4GHsMemo*)rt_malloc(nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
-                rt_memset(dHsMemo, 0, nb * (size_t)D4G_HSMEMO_SLOTS * sizeof(D4GHsMemo));
-                dPassMemo = (uint64_t*)rt_malloc((size_t)passMemoWords * 8 + 64);
-                rt_memset(dPassMemo, 0, (size_t)passMemoWords * 8 + 64);
-                dRcMemo = (D4GRecodeMemo*)rt_malloc(nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
-                rt_memset(dRcMemo, 0, nb * (size_t)D4G_RCMEMO_SLOTS * sizeof(D4GRecodeMemo));
             }
         }
     }
@@ -1221,6 +1231,7 @@ struct Batch {
     bool forceLevels = false;   // the round in hand fell back from the persistent executor
     std::vector<D4GRoundResult> run_round_legacy(const std::vector<int>& act) {
         Engine& E = engine();
+        ensure_legacy_tables();
         std::vector<D4GRoundResult> res(act.size());
         for (int pass = 0; pass < 2; pass++) {
             const Program& P = pass == 0 ? E.progDyn : E.progFixed;
