@@ -951,6 +951,8 @@ struct Batch {
         dSrc = (uint32_t*)rt_malloc((size_t)uTotal * 4 + 64);
         RtEvent e0, e1;
         e0.record();
+        int32_t* dBadFlags = nullptr;     // per stream: a back-reference reached before the start of the stream
+        std::vector<void*> later;         // device buffers the queued kernels still read: freed after the wait below
         if (!emits.empty()) {
             // 3. emit
             D4GEmitIn* dEm = (D4GEmitIn*)rt_malloc(emits.size() * sizeof(D4GEmitIn));
@@ -1026,15 +1028,23 @@ struct Batch {
             }
             RT_LAUNCH(k_resolve_streams, n * (size_t)G, 256, dStreams, dSrc, dU, G);
             stats.kernel_launches++;
+            // (no wait here: the bin statistics follow on the same stream; the flags come back behind them, one wait for both)
+            dBadFlags = dBad;
+            later = {dEm, dRanges, dChanged, jumpTmp[0], jumpTmp[1]};
+        }
+        later.push_back(block_bins(LY.realBlocks, needSlots));
+        e1.record();
+        if (dBadFlags) {
             std::vector<int32_t> bad(n);
-            rt_d2h(bad.data(), dBad, n * 4);
+            rt_d2h(bad.data(), dBadFlags, n * 4);
+            rt_free(dBadFlags);
+            for (void* q : later) rt_free(q);
             for (size_t i = 0; i < n; i++)
                 if (bad[i]) throw std::runtime_error("parse: back-reference before the start of stream (host check missed it)");
-            rt_free(dEm); rt_free(dRanges); rt_free(dBad); rt_free(dChanged); rt_free(jumpTmp[0]); rt_free(jumpTmp[1]);
+        } else {
+            rt_sync();
+            for (void* q : later) rt_free(q);
         }
-        block_bins(LY.realBlocks, needSlots);
-        e1.record();
-        rt_sync();
         msParseKernels += rt_elapsed_ms(e0, e1);
         rt_free(dSrc);
         dSrc = nullptr;
@@ -1044,15 +1054,15 @@ struct Batch {
     }
     // 5. static bin statistics of every block's back-reference records (the least-expensive pass works from them);
     //    also fills in the records' first decoded bytes
-    void block_bins(const std::vector<int32_t>& realBlocks, bool needSlots) {
-        if (!needSlots || realBlocks.empty()) return;
+    // (queued, not waited for: the caller frees the returned list after its next wait on the stream)
+    void* block_bins(const std::vector<int32_t>& realBlocks, bool needSlots) {
+        if (!needSlots || realBlocks.empty()) return nullptr;
         int32_t* dReal = (int32_t*)rt_malloc(realBlocks.size() * 4);
         rt_h2d(dReal, realBlocks.data(), realBlocks.size() * 4);
         D4GCtx c = make_ctx(engine().progDyn, 0);
         RT_LAUNCH(k_block_bins, realBlocks.size() * D4G_BINS_SPLIT, 256, c, dReal);
         stats.kernel_launches++;
-        rt_sync();
-        rt_free(dReal);
+        return dReal;
     }
 
     // One optimiseBlock call on every block of `act` (device block indices): runs the program

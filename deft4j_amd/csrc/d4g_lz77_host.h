@@ -371,8 +371,9 @@ struct LzFront {
             rt_sync();
             rt_free(dDst);
         }
-        B.block_bins(LY.realBlocks, optimise);
+        void* binList = B.block_bins(LY.realBlocks, optimise);
         rt_sync();
+        rt_free(binList);
         B.stats.ms_lz_sort = rt_elapsed_ms(e0, e1);
         B.stats.ms_lz_parse = rt_elapsed_ms(e1, e2);
         B.stats.ms_lz_emit = rt_elapsed_ms(e3, e4);
