@@ -2503,17 +2503,17 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
         __syncthreads();
         tp = prof ? clock64() : 0;
         if (!d4f_select(best, &P.results[(size_t)which * D4F_MAXROUNDS + rounds])) { info |= D4F_INFO_FALLBACK; break; }
-        if (prof) acc(26, clock64() - tp);
+        if (prof) { acc(26, clock64() - tp); if (rounds == 0) acc(63, clock64() - tKernel); }   // [63]: cycles of the blocks' first rounds
         rounds++;
         if (!F.improved) break;
         if (rounds >= P.maxRounds || rounds >= D4F_MAXROUNDS) { info |= D4F_INFO_MORE; break; }
     }
     __syncthreads();
-    if (prof) {   // [39] the slowest block, [40, 64) blocks by duration (0.5 M cycles per class), refs of the blocks in the slowest classes in [..]
+    if (prof) {   // [39] the slowest block, [40, 63) blocks by duration (0.5 M cycles per class)
         const long long dt = clock64() - tKernel;
         acc(29, dt);
         atomicMax((unsigned long long*)&P.stats[39], (unsigned long long)dt);
-        const int cls = (int)(dt / 500000) < 23 ? (int)(dt / 500000) : 23;
+        const int cls = (int)(dt / 500000) < 22 ? (int)(dt / 500000) : 22;
         acc(40 + cls, 1);
     }
     if (threadIdx.x == 0) P.roundInfo[which] = rounds | info;

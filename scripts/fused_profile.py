@@ -28,4 +28,5 @@ print("advance  %5.1f %%   set-up %5.1f %%   selection %5.1f %%" % (100.0 * buf[
 if buf[37]:
     print("tree batch (mean cycles): own literal tree %.0f  wait for the others %.0f  header %.0f  publish %.0f  (%.1f batches per round, %.1f rebuilds per round taken from an equal histogram)" % (buf[33] / buf[37], buf[34] / buf[37], buf[35] / buf[37], buf[36] / buf[37], buf[37] / rounds, buf[38] / rounds))
 print("ids per round: masks %.1f codes %.1f headers %.1f" % (buf[30] / rounds, buf[31] / rounds, buf[32] / rounds))
-print("slowest block %.0f cycles (%.2f ms); blocks by duration (0.21 ms classes): %s" % (buf[39], buf[39] / 2.4e6, " ".join(str(buf[40 + k]) for k in range(24))))
+print("slowest block %.0f cycles (%.2f ms); blocks by duration (0.21 ms classes): %s" % (buf[39], buf[39] / 2.4e6, " ".join(str(buf[40 + k]) for k in range(23))))
+print("first rounds: %.1f %% of the cycles" % (100.0 * buf[63] / tot))
