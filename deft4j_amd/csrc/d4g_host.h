@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -1000,7 +1001,29 @@ struct Batch {
                     rt_h2d(dTl, ord.data(), nt * sizeof(D4GJumpTile));
                     unsigned long long* dCh0 = (unsigned long long*)rt_malloc(16);
                     rt_memset(dCh0, 0, 16);
+#ifdef D4G_HOSTSIM
                     RT_LAUNCH(k_jump_tiles, nt, 256, dStreams, dTl, dSrc, tileReps, dCh0);
+#else
+                    {
+                        // 1024 threads per tile and 70 KiB of LDS the kernel never touches: at most two tiles per CU (one beside a
+                        // resident search workgroup), so the tiles of an XCD's CUs and their neighbours stay in its L2 over the
+                        // rounds (2.89 -> 2.66 ms of parse kernels at one tile per CU, 100 KiB; 70 KiB is what several batches in
+                        // flight like best: 12.5-13.0 -> 13.3-13.4 GB/s on config 2)
+                        static const int jt = env_int("D4G_JUMP_THREADS", 1024), jl = env_int("D4G_JUMP_LDS_KB", 70);
+                        if (jl > 64) {   // (more than 64 KiB of dynamic LDS has to be allowed once per device)
+                            static std::atomic<unsigned long long> allowed{0};
+                            int dev = 0;
+                            RT_CHECK(hipGetDevice(&dev));
+                            const unsigned long long bit = 1ull << (dev & 63);
+                            if (!(allowed.load() & bit)) {
+                                RT_CHECK(hipFuncSetAttribute((const void*)k_jump_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, jl * 1024));
+                                allowed.fetch_or(bit);
+                            }
+                        }
+                        hipLaunchKernelGGL(k_jump_tiles, dim3((unsigned)nt), dim3((unsigned)jt), (size_t)jl * 1024, rt().sa(), dStreams, dTl, dSrc, tileReps, dCh0);
+                        RT_CHECK(hipGetLastError());
+                    }
+#endif
                     stats.kernel_launches++;
                     jumpTmp[0] = dTl; jumpTmp[1] = dCh0;   // (freed with the other parse buffers, after the next synchronisation)
                 }

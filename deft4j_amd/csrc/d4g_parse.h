@@ -929,12 +929,14 @@ __global__ void __launch_bounds__(256) k_jump_streams(const D4GStreamDesc* strea
 // The first doubling rounds, tile by tile.  A round's gathers reach 32 KiB * 2^round back: for the first few rounds that is the
 // tile itself and a handful of tiles before it.  One workgroup owns one 32 Ki-entry tile and runs `reps` rounds over it in a
 // row while its neighbours (same XCD: consecutive tiles get workgroup ids that are equal mod 8) do the same to theirs, so the
-// entries and their targets are served by that XCD's L2 after the first touch instead of crossing to HBM every round.  In place
-// and unsynchronised like k_jump_streams: any value read is a position further up the same copy chain.
+// entries and their targets are served by that XCD's L2 after the first touch instead of crossing to HBM every round — as far as
+// the tiles in flight fit: the launch is 1024 threads per tile and asks for 70 KiB of (unused) LDS, two tiles per CU at most.  In
+// place and unsynchronised like k_jump_streams: any value read is a position further up the same copy chain.
 #define D4G_JUMP_TILE 32768
 struct D4GJumpTile { int32_t stream, pad; long long first; };
-__global__ void __launch_bounds__(256) k_jump_tiles(const D4GStreamDesc* streams, const D4GJumpTile* tiles, uint32_t* src, int reps,
+__global__ void __launch_bounds__(1024) k_jump_tiles(const D4GStreamDesc* streams, const D4GJumpTile* tiles, uint32_t* src, int reps,
                                                     unsigned long long* changed) {
+    // (the launch asks for LDS it does not use — d4g_host.h: that bounds the workgroups per CU, so that the tiles in flight stay in L2)
     const D4GJumpTile t = tiles[blockIdx.x];
     const D4GStreamDesc sd = streams[t.stream];
     uint32_t* s = src + sd.uBase;
