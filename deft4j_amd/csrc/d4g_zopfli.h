@@ -1244,6 +1244,24 @@ D4G_DEV uint32_t zf_rl(uint32_t v, int l) {
 D4G_DEV float zf_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 D4G_DEV uint32_t zf_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 #define ZF_NQ 10
+// Change points of a position: up to eight match lengths (ascending, at most 258), two to a word; an unused place holds ZF_NOCP.
+// zf_count_below = how many of them are below k: both halves of a word at once with the packed 16-bit instructions (a place is
+// below k when place - k is negative; nothing overflows: every value is below 2^15).
+#define ZF_NOCP 0x7fffu
+#define ZF_NOCP2 0x7fff7fffu
+D4G_DEV int zf_count_below(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int k) {
+#ifdef D4G_HOSTSIM
+    return ((int)(c0 & 0xffff) < k) + ((int)(c0 >> 16) < k) + ((int)(c1 & 0xffff) < k) + ((int)(c1 >> 16) < k) +
+           ((int)(c2 & 0xffff) < k) + ((int)(c2 >> 16) < k) + ((int)(c3 & 0xffff) < k) + ((int)(c3 >> 16) < k);
+#else
+    typedef short zf_s2 __attribute__((ext_vector_type(2)));
+    const zf_s2 kk = {(short)k, (short)k};
+    zf_s2 a, b, c, d;
+    __builtin_memcpy(&a, &c0, 4); __builtin_memcpy(&b, &c1, 4); __builtin_memcpy(&c, &c2, 4); __builtin_memcpy(&d, &c3, 4);
+    const zf_s2 t = ((a - kk) >> 15) + ((b - kk) >> 15) + ((c - kk) >> 15) + ((d - kk) >> 15);   // -1 per place below k
+    return -((int)t.x + (int)t.y);
+#endif
+}
 D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
     const ZfView& v = job.v;
     const int lane = threadIdx.x & 63;
@@ -1265,7 +1283,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
     if (lane == 0) C[0] = 0.f;
     int B = 0;                  // index of register 0, lane 0
     int loaded = -64;           // base the batch registers were prepared for
-    uint32_t rMeta = 0, rCl0 = 0xffffffffu, rCl1 = 0xffffffffu, rCl2 = 0xffffffffu, rCl3 = 0xffffffffu, rLitLo = 0, rLitHi = 0;
+    uint32_t rMeta = 0, rCl0 = ZF_NOCP2, rCl1 = ZF_NOCP2, rCl2 = ZF_NOCP2, rCl3 = ZF_NOCP2, rLitLo = 0, rLitHi = 0;
     bool afterShortcut = false;
     int j = 0;
     while (j < size) {
@@ -1280,7 +1298,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
         if (loaded != B) {
             LZ_WAVE_SYNC();
             const long long p = start + B + lane;
-            rMeta = 0; rCl0 = rCl1 = rCl2 = rCl3 = 0xffffffffu; rLitLo = rLitHi = 0;
+            rMeta = 0; rCl0 = rCl1 = rCl2 = rCl3 = ZF_NOCP2; rLitLo = rLitHi = 0;
             if (p < end) {
                 const uint32_t* e = zf_entry(v, p);
                 const uint4 a = *(const uint4*)e, b = *(const uint4*)(e + 4);
@@ -1289,7 +1307,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 int n = 0;
                 const bool link = (b.w & ZF_POOL_LINK) != 0;
                 for (int c = 0; c < 8; c++) {
-                    cl[c] = 0xffff;
+                    cl[c] = ZF_NOCP;
                     if (w[c] && !link) {
                         const int ds = d4g_dist2sym((int)(w[c] & 0xffff));
                         cl[c] = w[c] >> 16;
@@ -1334,20 +1352,25 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 if (kend >= 3) {
                     const double mca = mincost + cj;
                     const uint32_t c0 = zf_rl(rCl0, o), c1 = zf_rl(rCl1, o), c2 = zf_rl(rCl2, o), c3 = zf_rl(rCl3, o);
+                    auto relax = [&](int q, float& crq, uint32_t& lrq) D4G_LAMBDA_INLINE {
+                        const int k = 64 * q + lane - o;
+                        const double cq = (double)crq;
+                        const bool isM = k >= 3 && k <= kend && !(cq <= mca);
+                        if (__ballot(isM) != 0ull) {
+                            const int kk = isM ? k : 3;
+                            const int ci = zf_count_below(c0, c1, c2, c3, kk);
+                            const int ib = S.lbTab[kk] + S.cpDb[o][ci];
+                            const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
+                            if (isM && nc < cq) { crq = (float)nc; lrq = (uint32_t)k; }
+                        }
+                    };
+                    relax(0, cr[0], lr[0]);
+                    if (o + kend >= 64) {   // (one test for the usual case — every target in register 0 — instead of one per register)
+                        relax(1, cr[1], lr[1]);
+                        if (o + kend >= 128) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        if (q == 0 || o + kend >= 64 * q) {
-                            const int k = 64 * q + lane - o;
-                            const double cq = (double)cr[q];
-                            const bool isM = k >= 3 && k <= kend && !(cq <= mca);
-                            if (__ballot(isM) != 0ull) {
-                                const int kk = isM ? k : 3;
-                                const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
-                                               ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
-                                const int ib = S.lbTab[kk] + S.cpDb[o][ci];
-                                const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
-                                if (isM && nc < cq) { cr[q] = (float)nc; lr[q] = (uint32_t)k; }
-                            }
+                            for (int q = 2; q < 6; q++)
+                                if (o + kend >= 64 * q) relax(q, cr[q], lr[q]);
                         }
                     }
                 }
@@ -1398,8 +1421,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                         const bool isM = k >= 3 && k <= kend && !(cq <= mca);      // (targets already at the model's minimum are skipped, as published)
                         if (__ballot(isM) != 0ull) {
                             const int kk = isM ? k : 3;
-                            const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
-                                           ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                            const int ci = zf_count_below(c0, c1, c2, c3, kk);
                             const int ib = S.lbTab[kk] + S.cpDb[o][ci];
                             const double nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
                             if (isM && nc < cq) { C[q] = (float)nc; Ln[q] = (uint32_t)k; }
@@ -1408,7 +1430,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                 }
             } else {
                 const int qmax = (o + kend) >> 6;
-                uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu, c3 = 0xffffffffu;
+                uint32_t c0 = ZF_NOCP2, c1 = ZF_NOCP2, c2 = ZF_NOCP2, c3 = ZF_NOCP2;
                 if (ncp != 255) { c0 = zf_rl(rCl0, o); c1 = zf_rl(rCl1, o); c2 = zf_rl(rCl2, o); c3 = zf_rl(rCl3, o); }
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
@@ -1420,8 +1442,7 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
                         const int kk = isM ? k : 3;
                         double nc;
                         if (ncp != 255) {
-                            const int ci = ((int)(c0 & 0xffff) < kk) + ((int)(c0 >> 16) < kk) + ((int)(c1 & 0xffff) < kk) + ((int)(c1 >> 16) < kk) +
-                                           ((int)(c2 & 0xffff) < kk) + ((int)(c2 >> 16) < kk) + ((int)(c3 & 0xffff) < kk) + ((int)(c3 >> 16) < kk);
+                            const int ci = zf_count_below(c0, c1, c2, c3, kk);
                             const int ib = S.lbTab[kk] + S.cpDb[o][ci];
                             nc = fixedModel ? (double)ib + cj : (((double)ib + S.llTab[kk]) + S.cpDc[o][ci]) + cj;
                         } else {
