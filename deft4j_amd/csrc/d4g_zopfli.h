@@ -1337,26 +1337,25 @@ D4G_DEV void zf_best_lengths(ZfSqLds& S, const ZfSqJob& job, bool fixedModel) {
             uint32_t lr[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { cr[q] = C[q]; lr[q] = Ln[q]; }
-            for (; o < oEnd; o++) {
+            const int oTight = oEnd < 63 ? oEnd : 63;
+            for (; o < oTight; o++) {
                 const uint32_t meta = zf_rl(rMeta, o);
                 if (__builtin_expect((meta >> 24) != 0u, 0)) break;
                 const int leng = (int)(meta & 0xffff);
                 const int kend = leng >= 3 ? (leng < size - B - o ? leng : size - B - o) : 0;
                 const double cj = (double)zf_u2f(zf_rl(zf_f2u(cr[0]), o));
                 const double ncLit = zf_u2d((unsigned long long)zf_rl(rLitLo, o) | ((unsigned long long)zf_rl(rLitHi, o) << 32)) + cj;
-                // the literal: index o + 1 sits in register 0, or (o == 63) in lane 0 of register 1 (no branch: a taken scalar
-                // branch costs more than the second compare).  The matches' targets are other lanes (k >= 3): register 0's costs
-                // as doubles serve both.
-                const double a0 = (double)cr[0], a1 = (double)cr[1];
+                // the literal: index o + 1 sits in register 0 (position 63, whose literal lands in register 1, is left to the
+                // general code below).  The matches' targets are other lanes (k >= 3): register 0's costs as doubles serve both.
+                const double a0 = (double)cr[0];
                 if (lane == o + 1 && ncLit < a0) { cr[0] = (float)ncLit; lr[0] = 1; }
-                if (lane == o - 63 && ncLit < a1) { cr[1] = (float)ncLit; lr[1] = 1; }
                 if (__builtin_expect(kend >= 3, 1)) {
                     const double mca = mincost + cj;
                     const uint32_t c0 = zf_rl(rCl0, o), c1 = zf_rl(rCl1, o), c2 = zf_rl(rCl2, o), c3 = zf_rl(rCl3, o);
                     auto relax = [&](int q, float& crq, uint32_t& lrq) D4G_LAMBDA_INLINE {
                         const int k = 64 * q + lane - o;
                         const double cq = q == 0 ? a0 : (double)crq;
-                        const bool isM = k >= 3 && k <= kend && !(cq <= mca);
+                        const bool isM = (unsigned)(k - 3) <= (unsigned)(kend - 3) && !(cq <= mca);   // 3 <= k <= kend (kend >= 3 here)
                         if (__ballot(isM) != 0ull) {   // (worth its wait: dropping the test for register 0 costs 14 %)
                             const int kk = isM ? k : 3;
                             const int ci = zf_count_below(c0, c1, c2, c3, kk);
