@@ -351,6 +351,12 @@ __device__ int d4g_tree_finish(TreeMem<H, I, MAXN, IDB_, OVL>& m, int stride, in
 // `limit` goes through the serial DFS + limiter of d4g_tree_finish.
 // ---------------------------------------------------------------------------------------
 #define D4G_LAMBDA_INLINE __attribute__((always_inline))
+// The wave's vote on a condition.  (HIP's __ballot takes an int: a bool goes through 0 / 1 and a second compare.)
+#ifdef D4G_HOSTSIM
+D4G_DEV unsigned long long d4g_ballot(bool p) { return __ballot(p ? 1 : 0); }
+#else
+D4G_DEV unsigned long long d4g_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
 #ifdef D4G_HOSTSIM
 D4G_DEV int d4g_readlane(int v, int k) { return __shfl(v, k); }
 D4G_DEV int d4g_uniform(int v) { return __shfl(v, 0); }
@@ -471,7 +477,7 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
     for (int base = 0; base < numSymbols; base += 64) {
         int i = base + lane;
         int fv = i < numSymbols ? (int)freq(i) : 0;
-        unsigned long long um = __ballot(fv != 0);
+        unsigned long long um = d4g_ballot(fv != 0);
         while (um) {
             int bpos = __ffsll((long long)um) - 1;
             um &= um - 1;
@@ -609,7 +615,7 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
     for (int base = 0; base < numSymbols; base += 64) {
         const int i = base + lane;
         const unsigned f = i < numSymbols ? (unsigned)freq(i) : 0u;
-        used += __popcll(__ballot(f != 0));
+        used += __popcll(d4g_ballot(f != 0));
         total += f;
     }
     total = (unsigned long long)wave_sum_i64((long long)total);
@@ -636,7 +642,7 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
         // the slots from the root down to k: k's ancestor set (a lane constant of lane k) and the root
         const unsigned pLo = (unsigned)d4g_readlane((int)ancLo, k) | 1u, pHi = (unsigned)d4g_readlane((int)ancHi, k);
         const bool onPath = ((pLo & bitLo) | (pHi & bitHi)) != 0;
-        const bool pGreater = lane > 0 && (pv >> 8) > xw;     // the parent comes down into this slot
+        const bool pGreater = (lane > 0) & ((pv >> 8) > xw);     // the parent comes down into this slot
         const bool selfGreater = (hv >> 8) > xw;
         if (onPath) {
             if (pGreater) hv = pv;
@@ -651,16 +657,17 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
         const unsigned xw = x >> 8;
         const unsigned lv = (unsigned)__shfl((int)hv, leftLane & 63), rv = (unsigned)__shfl((int)hv, (leftLane + 1) & 63);
         const bool hasL = leftLane < s;
-        const bool right = leftLane + 1 < s && (lv >> 8) > (rv >> 8);
+        const bool right = (leftLane + 1 < s) & ((lv >> 8) > (rv >> 8));
         const unsigned cv = right ? rv : lv;
-        const unsigned long long Rm = __ballot(right), Hm = __ballot(hasL);
+        const unsigned long long Rm = d4g_ballot(right), Hm = d4g_ballot(hasL);
         // C: the slots that are the child their parent would hand up — slot 2P+1 when P hands up its left child, 2P+2 when
         // its right one (only P < 32 has children): the parents' bits spread to the even positions, on the scalar unit
         const unsigned long long C = (d4g_spread_bits((unsigned)(Hm & ~Rm)) << 1) | (d4g_spread_bits((unsigned)Rm) << 2);
         // on the root's hand-up path: this slot and all its ancestors (the root aside) are such children
-        const bool onPath = lane < s && ((unsigned)C & ancLo) == ancLo && ((unsigned)(C >> 32) & ancHi) == ancHi;
-        const bool pass = onPath && hasL && xw > (cv >> 8);
-        const bool stop = onPath && !pass && (lane == 0 || xw > (hv >> 8));
+        // (bitwise on purpose: a short-circuit here becomes an exec-mask region with a branch around it)
+        const bool onPath = (lane < s) & (((unsigned)C & ancLo) == ancLo) & (((unsigned)(C >> 32) & ancHi) == ancHi);
+        const bool pass = onPath & hasL & (xw > (cv >> 8));
+        const bool stop = onPath & !pass & ((lane == 0) | (xw > (hv >> 8)));
         if (pass) hv = cv;
         else if (stop) hv = x;
         return out;
@@ -670,7 +677,7 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
     for (int base = 0; base < numSymbols; base += 64) {
         const int i = base + lane;
         const int fv = i < numSymbols ? (int)freq(i) : 0;
-        unsigned long long um = __ballot(fv != 0);
+        unsigned long long um = d4g_ballot(fv != 0);
         while (um) {
             const int bpos = __ffsll((long long)um) - 1;
             um &= um - 1;

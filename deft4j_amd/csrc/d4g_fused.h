@@ -675,7 +675,7 @@ __device__ __forceinline__ void d4f_sweep_group(const int32_t* codes, int nk, in
                 e1 = t <= cost;
                 e0 = t < cost;
             }
-            const unsigned long long b1 = __ballot(e1), b0 = __ballot(e0);
+            const unsigned long long b1 = d4g_ballot(e1), b0 = d4g_ballot(e0);
             if (lane == 0) { stage[k][0][i] = b0; stage[k][1][i] = b1; }
         }
     }
@@ -687,7 +687,7 @@ __device__ __forceinline__ void d4f_sweep_group(const int32_t* codes, int nk, in
             d4f_eset(c, b, codes[k], 0)[w0 + lane] = v0;
             d4f_eset(c, b, codes[k], 1)[w0 + lane] = v1;
         }
-        if (__ballot(v0 != v1) && lane == 0) S.neq[k] = 1;
+        if (d4g_ballot(v0 != v1) && lane == 0) S.neq[k] = 1;
     }
     d4g_wave_sync();
 }
@@ -786,7 +786,7 @@ D4G_DEV int d4f_publish_mask(const D4GCtx& c, const D4GBlock& b, const D4FGlob& 
             const uint64_t* other = d4f_mask(c, b, id);
             int bad = 0;
             for (int w = lane; w < nWords; w += 64) bad |= mine[w] != other[w];
-            if (!__ballot(bad)) { found = id; break; }
+            if (!d4g_ballot(bad)) { found = id; break; }
         }
     }
     if (found >= 0) return found;
@@ -952,7 +952,7 @@ D4F_TASK void d4f_apply_task(int idx) {
             if (!leaf) d4f_rec_to_hist(W.hist, Ub, rv);
         });
         const int saved = wave_sum_i32(savedLane);
-        if (__ballot(bad) && lane == 0) atomicAdd(c.errors, 1);
+        if (d4g_ballot(bad) && lane == 0) atomicAdd(c.errors, 1);
         int mOut = m;
         if (!leaf) {
             uint64_t* O = d4f_mask(c, b, mNew);
@@ -1004,7 +1004,7 @@ D4F_TASK void d4f_apply_task(int idx) {
                           if (!leaf) d4f_rec_to_hist(W.hist, Ub, rv);
                       });
     const int saved = wave_sum_i32(savedLane);
-    if (__ballot(bad) && lane == 0) atomicAdd(c.errors, 1);
+    if (d4g_ballot(bad) && lane == 0) atomicAdd(c.errors, 1);
     int mOut = m;
     if (!leaf) {
         uint64_t* O = d4f_mask(c, b, mNew);
@@ -1328,7 +1328,7 @@ D4G_DEV int d4f_wave_cl_tree(unsigned char* treeMem, const uint32_t* clFreq, uin
 D4G_DEV int d4f_wave_trim(const uint8_t* clLen, int nCl) {
     const int lane = threadIdx.x & 63;
     const bool nz = lane < nCl && lane < 19 && clLen[D4G_CL_ORDER[lane]] != 0;
-    const unsigned long long m = __ballot(nz);
+    const unsigned long long m = d4g_ballot(nz);
     return m ? 64 - __clzll((long long)m) : nCl;
 }
 // rewriteHeader with the default flags — DeflateBlockHuffman.java:484-577 (wg_rewrite_header's wave part): pairs,
@@ -1349,7 +1349,7 @@ __device__ __forceinline__ int d4f_wave_default_header(const uint8_t* lens, int 
         int i = ch * 64 + lane;
         v[ch] = i < n ? len(i) : -1;
         int pv = (i > 0 && i < n) ? len(i - 1) : -2;
-        sm[ch] = __ballot(i < n && v[ch] != pv);
+        sm[ch] = d4g_ballot(i < n && v[ch] != pv);
     }
     int base = 0;
 #pragma unroll
@@ -1517,7 +1517,7 @@ D4F_TASK void d4f_tree_dist(int slotIdx, int m) {     // wave B of the slot: dis
     if (lane < 30 && T.hist[D4G_NLIT + lane]) md = lane + 1;
     const int lastDist = wave_max_i32(md);
     const bool used = lane < lastDist && T.hist[D4G_NLIT + lane] != 0;
-    const int nz = __popcll(__ballot(used));
+    const int nz = __popcll(d4g_ballot(used));
     int nDist, err = 0;
     if (lastDist == 0) nDist = 1;                                  // handleZero: new HuffmanTable(1)
     else if (nz <= 1) { nDist = lastDist; if (lane == 0) T.lens[D4G_NLIT + lastDist - 1] = 1; }   // handleOne: one used distance code, length 1
@@ -1571,7 +1571,7 @@ D4F_TASK void d4f_tree_publish(int slotIdx) {
             int bad = 0;
             for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) bad |= ((const uint32_t*)cd.lens)[i] != lw[i];
             if (lane == 0) bad |= cd.nLit != T.nLit || cd.nDist != T.nDist || cd.type != D4G_DYNAMIC;
-            if (!__ballot(bad)) { found = id; break; }
+            if (!d4g_ballot(bad)) { found = id; break; }
         }
     }
     int code = found;
@@ -1645,7 +1645,7 @@ D4F_TASK void d4f_hs_task(int slotIdx, int code) {
             int i = ch * 64 + lane;
             v[ch] = i < n ? (int)comb[i] : -1;
             int pv = (i > 0 && i < n) ? (int)comb[i - 1] : -2;
-            sm[ch] = __ballot(i < n && v[ch] != pv);
+            sm[ch] = d4g_ballot(i < n && v[ch] != pv);
         }
         int ncx = 0;
 #pragma unroll
@@ -1666,7 +1666,7 @@ D4F_TASK void d4f_hs_task(int slotIdx, int code) {
             bool simple = start && (v[ch] != 0 ? run <= 3 : run <= 2);
             bool cx = start && !simple;
             if (simple) atomicAdd(&H.baseFreq[v[ch]], (unsigned)run);
-            unsigned long long cm = __ballot(cx);
+            unsigned long long cm = d4g_ballot(cx);
             if (cx) {
                 int idx = ncx + __popcll(cm & ((1ULL << lane) - 1));
                 H.runV[idx] = (uint8_t)v[ch];
@@ -1749,7 +1749,7 @@ D4F_TASK void d4f_cl_work() {
         } else {
             for (int i = lane; i < D4G_HIST; i += 64) { const int v = (int)Wd[i]; if (v) atomicAdd(&T.delta[i], v); }
         }
-        if (__ballot(badLane) && lane == 0) atomicAdd(c.errors, 1);
+        if (d4g_ballot(badLane) && lane == 0) atomicAdd(c.errors, 1);
         d4g_wave_sync();
     };
     for (;;) {
@@ -2174,7 +2174,7 @@ D4F_TASK bool d4f_round_setup(const D4GOp* ops0, const D4GOp* ops1, int nOps0, i
                 int bad = ((const uint32_t*)cd.lens)[lane] != w0;
                 if (lane < 16) bad |= ((const uint32_t*)cd.lens)[64 + lane] != w1;
                 if (lane == 0) bad |= cd.nLit != nLit0 || cd.nDist != nDist0 || cd.type != curType;
-                if (!__ballot(bad)) { found = id; break; }
+                if (!d4g_ballot(bad)) { found = id; break; }
             }
         }
         const int nCodeNow = __shfl(F.nCode, 0);
@@ -2414,7 +2414,7 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
                     if (from >= 0) {
                         int diff = 0;
                         for (int i = lane; i < D4G_HIST; i += 64) diff |= F.G.hist[(size_t)m * D4G_HIST + i] != F.G.hist[(size_t)from * D4G_HIST + i];
-                        if (__ballot(diff)) from = -1;
+                        if (d4g_ballot(diff)) from = -1;
                     }
                     d4g_wave_sync();
                     if (lane == 0) F.treeCand[0][t] = from;

@@ -457,14 +457,14 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
             total = lc[x & 255u] + lc[(x >> 8) & 255u] + lc[(x >> 16) & 255u] + (len > 3 ? lc[x >> 24] : 0);
         }
         bool undec = act && total < lim && len > 4;
-        if (__ballot(undec)) {
+        if (d4g_ballot(undec)) {
             if (undec) {   // bytes 4-7, also from the record
                 const uint32_t x = rec.w;
                 const int n = len - 4;
                 total += lc[x & 255u] + (n > 1 ? lc[(x >> 8) & 255u] : 0) + (n > 2 ? lc[(x >> 16) & 255u] : 0) + (n > 3 ? lc[x >> 24] : 0);
                 undec = total < lim && len > 8;
             }
-            if (__ballot(undec)) {
+            if (d4g_ballot(undec)) {
                 if (undec) {   // the rare long walk: the rest comes from U, four bytes per step
                     D4GLitWalk lw;
                     lw_start(lw, Uw, rec.y + 8, len - 8);
@@ -482,7 +482,7 @@ __device__ __forceinline__ void wg_replace_backrefs(D4GLds* L, const D4GCtx& c, 
             atomicSub(&S->hist[D4G_NLIT + ref_dsym(a)], 1u);
             for_bytes(Ub + rec.y, len, [&](int by) { atomicAdd(&S->hist[by], 1u); return true; });
         }
-        uint64_t nm = __ballot(bit);
+        uint64_t nm = d4g_ballot(bit);
         if (lane == 0) {
             st_sc1(maskOut + w0, nm);
             if (mine) st_sc1((uint64_t*)mine + D4G_PASSMEMO_HDR_WORDS + w0, nm);
@@ -550,11 +550,11 @@ __global__ void __launch_bounds__(256) k_block_bins(D4GCtx c, const int32_t* blo
             for_bytes(Ub + rv.y, len, [&](int by) { atomicAdd(&row[by], 1u); return true; });
         }
         // the bin masks: one ballot per bin present in this word of records
-        unsigned long long todo = __ballot(len > 0);
+        unsigned long long todo = d4g_ballot(len > 0);
         while (todo) {
             int src = __ffsll((long long)todo) - 1;
             int bsel = __shfl(bin, src);
-            unsigned long long same = __ballot(len > 0 && bin == bsel);
+            unsigned long long same = d4g_ballot(len > 0 && bin == bsel);
             if (lane == src) bm[(long long)bsel * nWords + (r >> 6)] = same;
             todo &= ~same;
         }
@@ -825,7 +825,7 @@ __device__ __forceinline__ void w0_remove_trailing_header_codes(D4GState* S) {
     const int lane = threadIdx.x & 63;
     const int nCl = S->nCl;
     bool nz = lane < nCl && lane < 19 && S->clLen[D4G_CL_ORDER[lane]] != 0;
-    unsigned long long m = __ballot(nz);
+    unsigned long long m = d4g_ballot(nz);
     int n = m ? 64 - __clzll((long long)m) : nCl;
     if (lane == 0) {
         long long saved = 3LL * (nCl - n);
@@ -864,7 +864,7 @@ __device__ __forceinline__ void wg_rewrite_header(D4GLds* L, int flags) {
             int i = ch * 64 + lane;
             v[ch] = i < n ? len(i) : -1;
             int pv = (i > 0 && i < n) ? len(i - 1) : -2;
-            sm[ch] = __ballot(i < n && v[ch] != pv);   // runs may span the literal/distance boundary — A.4
+            sm[ch] = d4g_ballot(i < n && v[ch] != pv);   // runs may span the literal/distance boundary — A.4
         }
         int base = 0;
 #pragma unroll
@@ -974,7 +974,7 @@ __device__ __forceinline__ void wg_recode_header(D4GLds* L) {
         // trim from the current count (trim_codelens: keep everything up to the last non-zero length)
         const int nCl0 = S->nCl;
         bool nz = lane < nCl0 && lane < 19 && S->clLen[D4G_CL_ORDER[lane]] != 0;
-        unsigned long long m = __ballot(nz);
+        unsigned long long m = d4g_ballot(nz);
         const int nCl = m ? 64 - __clzll((long long)m) : nCl0;
         int hbl = 0;
         for (int i = lane; i < np; i += 64) {
@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void wg_recode_huffman(D4GLds* L, D4GRecodeMemo* memo
     }
     if (wv == (blockDim.x > 64 ? 1 : 0)) {
         bool used = ln < lastDist && S->hist[D4G_NLIT + ln] != 0;
-        int nz = __popcll(__ballot(used));
+        int nz = __popcll(d4g_ballot(used));
         if (lastDist == 0) {  // handleZero: new HuffmanTable(1)
             if (ln == 0) S->nDist = 1;
         } else if (nz <= 1) {  // handleOne: one used distance code, length 1
@@ -1724,7 +1724,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
                 bool bad = false;
                 for (int i = lane; i < (D4G_NLIT + D4G_NDIST) / 4; i += 64) bad |= ld_sc1(&e->key[i]) != cw[i];
                 if (lane == 0) bad |= ld_state_i32(&e->nLit) != nLit || ld_state_i32(&e->n) != n;
-                if (__ballot(bad)) found = -1;             // same hashes, different lengths: compute without the memo
+                if (d4g_ballot(bad)) found = -1;             // same hashes, different lengths: compute without the memo
             }
         }
         if (found >= 0) {
@@ -1747,7 +1747,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
             int i = ch * 64 + lane;
             v[ch] = i < n ? (int)comb[i] : -1;
             int pv = (i > 0 && i < n) ? (int)comb[i - 1] : -2;
-            sm[ch] = __ballot(i < n && v[ch] != pv);
+            sm[ch] = d4g_ballot(i < n && v[ch] != pv);
         }
         int ncx = 0;
 #pragma unroll
@@ -1768,7 +1768,7 @@ __device__ void d4g_exec_hdr_search(D4GHdrLds& H, uint8_t* comb, const D4GCtx& c
             bool simple = start && (v[ch] != 0 ? run <= 3 : run <= 2);
             bool cx = start && !simple;
             if (simple) atomicAdd(&H.baseFreq[v[ch]], (unsigned)run);
-            unsigned long long cm = __ballot(cx);
+            unsigned long long cm = d4g_ballot(cx);
             if (cx) {
                 int idx = ncx + __popcll(cm & ((1ULL << lane) - 1));
                 H.runV[idx] = (uint8_t)v[ch];
