@@ -391,6 +391,15 @@ struct D4GWaveHeap {
         if (k < 64) regPut(k, ww, ii);
         else if ((threadIdx.x & 63) == 0) deep[k] = ((uint64_t)ww << 32) | (uint32_t)ii;
     }
+    // slots k and k + 1 (k + 1 may be one past the queue's end: still inside the array, the caller ignores it): both LDS reads
+    // go out before either is waited for
+    D4G_DEV void get2(int k, unsigned& w0o, int& i0o, unsigned& w1o, int& i1o) const {
+        if (k >= 64) {
+            const uint64_t e0 = deep[k], e1 = deep[k + 1];
+            w0o = (unsigned)d4g_uniform((int)(e0 >> 32)); i0o = d4g_uniform((int)(uint32_t)e0);
+            w1o = (unsigned)d4g_uniform((int)(e1 >> 32)); i1o = d4g_uniform((int)(uint32_t)e1);
+        } else { get(k, w0o, i0o); get(k + 1, w1o, i1o); }
+    }
 };
 
 #if defined(D4G_PROFILE_OPS) && !defined(D4G_HOSTSIM)
@@ -444,7 +453,11 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
                 const bool right = li + 1 < s && lwv > rwv;
                 const int cidx = right ? li + 1 : li;
                 const int cwv = (int)(right ? rwv : lwv);
-                while (k < regHalf) {
+                // (bounded and unrolled — at most five register levels, slots 0..30 — instead of a while loop: a taken
+                // back-edge costs a lone wave ~45 cycles per level)
+#pragma unroll
+                for (int lev = 0; lev < 5; lev++) {
+                    if (k >= regHalf) break;
                     int child = d4g_readlane(cidx, k);
                     unsigned cw = (unsigned)d4g_readlane(cwv, k);
                     if (xw <= cw) { placed = true; break; }
@@ -453,15 +466,13 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
                 }
             }
             if (!placed) {
-                while (k < half) {   // the rest of the path (slots in LDS)
+#pragma unroll
+                for (int lev = 0; lev < 6; lev++) {   // the rest of the path (slots in LDS): at most 2^11 slots
+                    if (k >= half) break;
                     int child = 2 * k + 1;
-                    unsigned cw; int ci;
-                    hp.get(child, cw, ci);
-                    if (child + 1 < s) {
-                        unsigned rw2; int ri2;
-                        hp.get(child + 1, rw2, ri2);
-                        if (cw > rw2) { cw = rw2; ci = ri2; child = child + 1; }
-                    }
+                    unsigned cw, rw2; int ci, ri2;
+                    hp.get2(child, cw, ci, rw2, ri2);
+                    if (child + 1 < s && cw > rw2) { cw = rw2; ci = ri2; child = child + 1; }
                     if (xw <= cw) break;
                     hp.put(k, cw, ci);
                     k = child;

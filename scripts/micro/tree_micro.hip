@@ -33,14 +33,29 @@ int main() {
     uint32_t* dh; uint8_t* dl; long long* dt;
     hipMalloc(&dh, 4 * D4G_NLIT); hipMalloc(&dl, D4G_NLIT); hipMalloc(&dt, 64);
     hipMemcpy(dh, h.data(), 4 * D4G_NLIT, hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 3; rep++) {
+    for (int big = 0; big < 2; big++) {
+    if (big) {   // a PNG-like block: every literal used, a few length symbols
+        unsigned t = 99;
+        for (int i = 0; i < 256; i++) { t = t * 1664525u + 1013904223u; h[i] = 20 + (t >> 20) % 400; }
+        h[256] = 1;
+        for (int i = 257; i < 280; i++) { t = t * 1664525u + 1013904223u; h[i] = 1 + (t >> 20) % 200; }
+        hipMemcpy(dh, h.data(), 4 * D4G_NLIT, hipMemcpyHostToDevice);
+    }
+    for (int rep = 0; rep < 2; rep++) {
         const int reps = 200;
         hipLaunchKernelGGL(k_tree, dim3(1), dim3(64), 0, 0, dh, dl, dt, reps);
         hipDeviceSynchronize();
         long long t[2]; hipMemcpy(t, dt, 16, hipMemcpyDeviceToHost);
         std::vector<uint8_t> l(D4G_NLIT); hipMemcpy(l.data(), dl, D4G_NLIT, hipMemcpyDeviceToHost);
         unsigned ck = 0; for (int i = 0; i < D4G_NLIT; i++) ck = ck * 31 + l[i];
-        printf("variant %d: %.0f cycles per tree (57 leaves), err %lld, lens checksum %08x\n", VARIANT, (double)t[0] / reps, t[1], ck);
+        int used = 0; for (int i = 0; i < D4G_NLIT; i++) used += h[i] != 0;
+#ifdef D4G_PROFILE_OPS
+        unsigned long long sec[4]; hipMemcpyFromSymbol(sec, HIP_SYMBOL(d4g_dbg_tree), sizeof(sec));
+        unsigned long long zero[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(d4g_dbg_tree), zero, sizeof(zero));
+        if (used > 64) printf("  sections (cycles per tree): leaves %.0f merges %.0f depths %.0f\n", (double)sec[0] / reps, (double)sec[1] / reps, (double)sec[2] / reps);
+#endif
+        printf("variant %d: %.0f cycles per tree (%d leaves), err %lld, lens checksum %08x\n", VARIANT, (double)t[0] / reps, used, t[1], ck);
+    }
     }
     return 0;
 }
