@@ -1489,7 +1489,7 @@ D4F_TASK void d4f_hdr_task(int idx) {
 // Huffman rebuild of a mask's histogram (one wave): recodeHuffman — DeflateBlockHuffman.java:670-743 — into the task's
 // scratch; ids are given afterwards by d4f_tree_publish.
 // ---------------------------------------------------------------------------------------
-D4F_TASK void d4f_tree_lit(int slotIdx, int m) {      // wave A of the slot: literal/length tree
+D4F_TASK void d4f_tree_lit(int slotIdx, int m) {      // the slot's first wave: literal/length tree
     D4FLds& F = d4fLds;
     D4F_CTX;
     D4FTreeScr& T = F.scr.tree[slotIdx];
@@ -1506,7 +1506,7 @@ D4F_TASK void d4f_tree_lit(int slotIdx, int m) {      // wave A of the slot: lit
     if (lane == 0) { T.nLit = lastLit; T.err = err; T.m = m; }
     d4g_wave_sync();
 }
-D4F_TASK void d4f_tree_dist(int slotIdx, int m) {     // wave B of the slot: distance tree
+D4F_TASK void d4f_tree_dist(int slotIdx, int m) {     // the slot's second wave: distance tree
     D4FLds& F = d4fLds;
     D4F_CTX;
     D4FTreeScr& T = F.scr.tree[slotIdx];
@@ -2434,17 +2434,20 @@ __device__ __forceinline__ void d4f_block_rounds(const D4FParams& P) {
                 const int nu = F.misc[3];
                 if (prof) acc(38, nq - nu);
                 const int nts = (nw >> 1) < D4F_TREE_SLOTS ? (nw >> 1) : D4F_TREE_SLOTS;   // (at least two waves per workgroup)
+                // waves 0 .. nts-1 build the literal/length trees, waves nts .. 2 nts-1 the distance trees: the long builds
+                // then sit on different SIMDs (wave w runs on SIMD w mod 4) instead of two to a SIMD
+                const bool distWave = wave >= nts;
+                const int ts = distWave ? wave - nts : wave;
                 for (int t0 = 0; t0 < nu; t0 += nts) {
-                    const int ts = wave >> 1;
                     long long tq = prof ? clock64() : 0;
                     if (ts < nts && t0 + ts < nu) {
                         const int m = Q[t0 + ts];
-                        if (wave & 1) d4f_tree_dist(ts, m); else d4f_tree_lit(ts, m);
+                        if (distWave) d4f_tree_dist(ts, m); else d4f_tree_lit(ts, m);
                     }
                     if (prof) { acc(33, clock64() - tq); tq = clock64(); }
                     __syncthreads();
                     if (prof) { acc(34, clock64() - tq); tq = clock64(); }
-                    if (ts < nts && t0 + ts < nu && !(wave & 1)) d4f_tree_header(ts);
+                    if (ts < nts && t0 + ts < nu && !distWave) d4f_tree_header(ts);
                     __syncthreads();
                     if (prof) { acc(35, clock64() - tq); tq = clock64(); }
                     if (wave == 0)
