@@ -583,6 +583,176 @@ __device__ int d4g_build_tree_wave(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSym
 }
 
 // ---------------------------------------------------------------------------------------
+// The same tree for 65 .. 127 leaves (text with capitals, digits and punctuation; many binary formats): the queue with every
+// lane holding the root-to-leaf path of "its" leaf position.  Level d (0..6) of the implicit heap has 2^d slots; register R[d]
+// of lane L holds slot 2^d - 1 + (L >> (6 - d)): a slot of level d is replicated over the 2^(6-d) lanes below it.  offer() is
+// lane-local (a lane sees its slot and the slot's parent in its own registers); poll() needs one exchange per level with the
+// lane that holds the sibling subtree (lane ^ 2^(5-d)).  Empty slots hold 0xffffffff; an entry is weight << 8 | node id, node
+// ids below 255, weights below 2^24.  Slower than the one-register queue below for up to 64 leaves (twelve instructions per
+// level of a poll), several times faster than the general queue above, whose deep slots live in LDS.
+// ---------------------------------------------------------------------------------------
+#define D4G_RP_INF 0xffffffffu
+template <int D> D4G_DEV unsigned d4g_rp_sibling(unsigned v) {   // the value held by the lane 2^(5-D) away
+#ifdef D4G_HOSTSIM
+    return (unsigned)__shfl_xor((int)v, 32 >> D);
+#else
+    if (D == 0) return (unsigned)__shfl_xor((int)v, 32);
+    if (D == 1) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                  // swap with lane ^ 16
+    if (D == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, false);    // row_ror:8
+    if (D == 3) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                  // swap with lane ^ 4
+    if (D == 4) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, false);                  // quad_perm [1,0,3,2]
+#endif
+}
+struct D4GPathHeap {
+    unsigned R[7];
+    unsigned mA[6];   // 0xff where this lane's slot of level d + 1 is a right child
+    int hs, lane;
+    D4G_DEV void init() {
+        lane = threadIdx.x & 63;
+        hs = 0;
+#pragma unroll
+        for (int d = 0; d < 7; d++) R[d] = D4G_RP_INF;
+#pragma unroll
+        for (int d = 0; d < 6; d++) mA[d] = ((lane >> (5 - d)) & 1) ? 0xffu : 0u;
+    }
+    // x = weight << 8 | id with id larger than every id in the queue: equal weights then compare as "x is not smaller" (siftUp's
+    // x >= e).  Every level reads its parent's old value: a parent heavier than x comes down, x lands in the topmost slot
+    // heavier than it (the slot being filled holds 0xffffffff).
+    D4G_DEV void offer(unsigned x) {
+        const int k = hs++;
+        const int D = 31 - __builtin_clz((unsigned)(k + 1));
+        const int Lk = (k + 1 - (1 << D)) << (6 - D);
+        const unsigned z = (unsigned)(lane ^ Lk);
+#pragma unroll
+        for (int d = 6; d >= 1; d--) {
+            const unsigned xd = z < (1u << (6 - d)) ? x : D4G_RP_INF;
+            const unsigned keep = R[d] < xd ? R[d] : xd;
+            R[d] = R[d - 1] > xd ? R[d - 1] : keep;
+        }
+        R[0] = R[0] < x ? R[0] : x;
+    }
+    template <int D> D4G_DEV unsigned sib(unsigned v) { return d4g_rp_sibling<D>(v); }
+    template <int D> D4G_DEV void sift(int s) {   // the last slot s (on level D >= 1) is taken out and sifted down from the root
+        const int Ls = (s + 1 - (1 << D)) << (6 - D);
+        const unsigned x = (unsigned)d4g_readlane((int)R[D], Ls);
+        const unsigned zs = (unsigned)(lane ^ Ls);
+        R[D] = zs < (1u << (6 - D)) ? D4G_RP_INF : R[D];
+        unsigned y = x;   // what arrives at (or already sits in) this lane's slot of the level in hand
+#define D4G_RP_LEVEL(d)                                                                                                        \
+        if ((d) < D) {                                                                                                         \
+            const unsigned A = R[(d) + 1], B = sib<(d) < 6 ? (d) : 5>(A);                                                      \
+            const bool own = (A | mA[(d) < 6 ? (d) : 5]) < (B | (mA[(d) < 6 ? (d) : 5] ^ 0xffu));   /* left unless left > right */ \
+            const unsigned cv = own ? A : B;                                                                                   \
+            const bool pass = (cv | 0xffu) < y;   /* x heavier than the child handed up (never true where x has not arrived) */ \
+            R[(d)] = pass ? cv : y;                                                                                            \
+            y = (pass && own) ? y : A;                                                                                         \
+        }
+        D4G_RP_LEVEL(0) D4G_RP_LEVEL(1) D4G_RP_LEVEL(2) D4G_RP_LEVEL(3) D4G_RP_LEVEL(4) D4G_RP_LEVEL(5)
+#undef D4G_RP_LEVEL
+        R[D] = y;
+    }
+    D4G_DEV unsigned poll() {
+        const unsigned out = (unsigned)d4g_readlane((int)R[0], 0);
+        const int s = --hs;
+        if (s == 0) { R[0] = D4G_RP_INF; return out; }
+        const int D = 31 - __builtin_clz((unsigned)(s + 1));
+        if (D == 6) sift<6>(s);
+        else if (D == 5) sift<5>(s);
+        else if (D == 4) sift<4>(s);
+        else if (D == 3) sift<3>(s);
+        else if (D == 2) sift<2>(s);
+        else sift<1>(s);
+        return out;
+    }
+};
+// used leaves (with the dummies) at most 127, total weight below 2^24 - 4: checked by the caller
+template <typename H, typename I, int MAXN, int IDB_, bool OVL, typename FreqFn, typename OutFn>
+__device__ int d4g_build_tree_wave_path(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numSymbols, int limit, FreqFn freq, OutFn outLen) {
+    const int SIDE = TreeMem<H, I, MAXN, IDB_, OVL>::SIDE;
+    const int lane = threadIdx.x & 63;
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    D4GPathHeap hp;
+    hp.init();
+    int nl = 0;
+    for (int base = 0; base < numSymbols; base += 64) {
+        const int i = base + lane;
+        const int fv = i < numSymbols ? (int)freq(i) : 0;
+        unsigned long long um = d4g_ballot(fv != 0);
+        while (um) {
+            const int bpos = __ffsll((long long)um) - 1;
+            um &= um - 1;
+            const unsigned f = (unsigned)d4g_readlane(fv, bpos);
+            if (lane == 0) m.value[nl] = (I)(base + bpos);
+            hp.offer((f << 8) | (unsigned)nl);
+            nl++;
+        }
+    }
+    int index = 0;
+    while (hp.hs < 2) {  // dummy leaves — HuffmanTree.java:50-58
+        bool unused = index >= numSymbols;
+        if (!unused) unused = d4g_uniform((int)freq(index)) == 0;
+        if (unused) {
+            if (lane == 0) m.value[nl] = (I)index;
+            hp.offer((1u << 8) | (unsigned)nl);
+            nl++;
+        }
+        index++;
+    }
+    int nn = nl;
+    for (int i = 0; i < nl - 1; i++) {
+        const unsigned a = hp.poll(), b = hp.poll();
+        const int l = (int)(a & 255u), r = (int)(b & 255u);
+        const int id = nn++;
+        if (lane == 0) {
+            m.left[id - nl] = (I)l;
+            m.right[id - nl] = (I)r;
+            m.parent[l] = (I)id;
+            m.parent[r] = (I)(id | SIDE);
+        }
+        hp.offer((((a >> 8) + (b >> 8)) << 8) | (unsigned)id);
+    }
+    const int root = (int)(hp.poll() & 255u);
+    d4g_wave_sync();
+    // leaf depths: two leaves per lane walk to the root
+    int dep[2] = {0, 0};
+    int maxDepth = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int leaf = r * 64 + lane;
+        if (leaf < nl) {
+            int node = leaf, d = 0;
+            while (node != root) { node = m.parent[node] & ~SIDE; d++; }
+            dep[r] = d;
+        }
+        maxDepth = dep[r] > maxDepth ? dep[r] : maxDepth;
+    }
+    maxDepth = wave_max_i32(maxDepth);
+    if (maxDepth > limit) {
+        int err = 0;
+        if (lane == 0) err = d4g_tree_finish(m, 1, 0, nl, root, numSymbols, limit, outLen);
+#ifndef D4G_HOSTSIM
+        __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
+        return __shfl(err, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int leaf = r * 64 + lane;
+        if (leaf < nl) {
+            const int v = m.value[leaf];
+            if (v < numSymbols) outLen(v, dep[r]);
+        }
+    }
+#ifndef D4G_HOSTSIM
+    __builtin_amdgcn_s_setprio(D4G_BASE_PRIO);
+#endif
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // The same tree again for the common case of at most 64 leaves and weights below 2^24 (a text block uses ~55 of the
 // literal/length symbols; the distance and code-length alphabets always fit): the whole priority queue is ONE register,
 // slot k = lane k, entry = weight << 8 | node id, and offer / poll are done by all lanes at once instead of one sift
@@ -630,7 +800,8 @@ __device__ int d4g_build_tree_wave64(TreeMem<H, I, MAXN, IDB_, OVL>& m, int numS
         total += f;
     }
     total = (unsigned long long)wave_sum_i64((long long)total);
-    if (used > 64 || total >= (1ull << 24) - 4) return d4g_build_tree_wave<NREG>(m, numSymbols, limit, freq, outLen);
+    if (used > 127 || total >= (1ull << 24) - 4) return d4g_build_tree_wave<NREG>(m, numSymbols, limit, freq, outLen);
+    if (used > 64) return d4g_build_tree_wave_path(m, numSymbols, limit, freq, outLen);   // (ids stay below 255: at most 127 leaves + 126 merges)
 #ifndef D4G_HOSTSIM
     __builtin_amdgcn_s_setprio(3);
 #endif
